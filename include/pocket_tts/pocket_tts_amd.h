@@ -1,0 +1,124 @@
+/*
+ * Additive C entry points of the MI355X engine.  Nothing here changes the drop-in surface of
+ * pocket_tts_c.h; these calls expose (1) options the reference can only set from C++ or its CLI,
+ * (2) a batch ingress for many independent utterances, and (3) one entry point per ONNX Runtime
+ * call site of the reference so each network can be checked in isolation.  All buffers are host
+ * memory; sizes are in elements.  Return value 0 = success, -1 = failure with the message available
+ * from pocket_tts_get_last_error(), unless stated otherwise.
+ */
+#ifndef POCKET_TTS_AMD_H
+#define POCKET_TTS_AMD_H
+
+#include "pocket_tts_c.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Full option set of the C++ PocketTTSConfig (include/pocket_tts/pocket_tts.hpp:58-68) plus device
+ * placement.  Unlike PocketTTSConfig, temperature is taken literally, so 0 selects the deterministic
+ * zero start point of src/pocket_tts.cpp:606-613 (the reference reaches that only through its CLI,
+ * src/main.cpp:49-50). */
+typedef struct {
+    const char* models_dir;      /* NULL: "models/onnx" */
+    const char* tokenizer_path;  /* NULL: "models/tokenizer.model"; "" or "none": no tokenizer (id-based calls only) */
+    const char* precision;       /* NULL: "int8"; "fp32", "bf16" */
+    const char* pack_path;       /* NULL: <models_dir>/pocket_tts.ptts */
+    float temperature;
+    int lsd_steps;               /* <= 0: 10  */
+    int max_frames;              /* <= 0: 500 */
+    int frames_after_eos;        /* < 0: 3    */
+    int device;                  /* HIP device ordinal */
+    int max_text_tokens;         /* <= 0: 512 */
+    int has_seed;                /* non-zero: seed the noise generator with `seed` */
+    unsigned long long seed;
+} PocketTTSConfigEx;
+
+POCKET_TTS_API PocketTTSHandle pocket_tts_create_ex(const PocketTTSConfigEx* config);
+
+/* dims[0..7] = latent_dim, d_model, samples_per_frame, vocab, mimi_dim, sample_rate, lsd_steps, max_frames */
+POCKET_TTS_API int pocket_tts_dims(PocketTTSHandle handle, int* dims);
+
+/* Voice handle <-> raw conditioning rows [frames][d_model]. */
+POCKET_TTS_API VoiceHandle pocket_tts_voice_from_embeddings(const float* embeddings, int frames, int d_model);
+POCKET_TTS_API int pocket_tts_voice_frames(VoiceHandle voice);
+POCKET_TTS_API const float* pocket_tts_voice_data(VoiceHandle voice);
+
+/* n utterances generated in lock step on one GPU (offline schedule of src/pocket_tts.cpp:548-657 for each).
+ * results[i] is filled like pocket_tts_generate does; release each with pocket_tts_free_audio. */
+POCKET_TTS_API int pocket_tts_generate_batch(PocketTTSHandle handle, int n, const char* const* texts,
+                                             const VoiceHandle* voices, AudioResult* results);
+
+/* Same, from token ids (the output of the text pre-step, src/tokenizer.cpp:27-60) and raw conditioning rows.
+ * noise[i]: NULL, or [max_frames][latent_dim] start points used instead of the internal generator.
+ * latents_out[i]: NULL, or room for max_frames*latent_dim floats; eos_out[i]: NULL or max_frames floats.
+ * frames_out[i] receives the frame count, eos_count_out[i] (may be NULL) the number of logits written. */
+POCKET_TTS_API int pocket_tts_generate_ids(PocketTTSHandle handle, int n, const long long* const* ids, const int* n_ids,
+                                           const float* const* voices, const int* voice_frames,
+                                           const float* const* noise, AudioResult* results, float* const* latents_out,
+                                           float* const* eos_out, int* frames_out, int* eos_count_out);
+
+/* pocket_tts_generate_ids in three parts, for callers that time or overlap the device-resident middle:
+ *   stage : host -> HBM copy of ids, conditioning rows and start points; returns a batch owned by the engine
+ *           (valid until the next stage / generate call with the same n on this handle), or NULL;
+ *   run   : prefill + frame loop + chunked decode; audio stays in HBM; frames_out[i] = frames of utterance i;
+ *   fetch : HBM -> host; fills results[i] (release with pocket_tts_free_audio) and, if given, latents_out[i]. */
+POCKET_TTS_API void* pocket_tts_stage_ids(PocketTTSHandle handle, int n, const long long* const* ids, const int* n_ids,
+                                          const float* const* voices, const int* voice_frames, const float* const* noise);
+POCKET_TTS_API int pocket_tts_run_staged(PocketTTSHandle handle, void* staged, int* frames_out);
+POCKET_TTS_API int pocket_tts_fetch_staged(PocketTTSHandle handle, void* staged, const int* frames, AudioResult* results,
+                                           float* const* latents_out);
+
+/* Streaming from token ids; same schedule and callback contract as pocket_tts_generate_streaming.
+ * Returns total samples or -1. */
+POCKET_TTS_API int pocket_tts_streaming_ids(PocketTTSHandle handle, const long long* ids, int n_ids, const float* voice,
+                                            int voice_frames, const float* noise, int chunk_size_frames,
+                                            AudioChunkCallbackC callback, void* user_data);
+
+/* Text pre-step alone: normalisation + SentencePiece ids (src/tokenizer.cpp:27-60).
+ * Returns the id count (may exceed cap; only cap ids are written) or -1. */
+POCKET_TTS_API int pocket_tts_tokenize(PocketTTSHandle handle, const char* text, long long* ids, int cap);
+
+/* ---- one entry point per reference graph call ------------------------------------------------- */
+
+/* text_conditioner: ids[T] -> out[T][d_model]                       (src/pocket_tts.cpp:299-320) */
+POCKET_TTS_API int ptts_text_conditioner(PocketTTSHandle handle, const long long* ids, int T, float* out);
+
+/* Recurrent state of `batch` lock-step utterances (LM KV caches + decoder state), zero-initialised
+ * like the reference's initState (src/pocket_tts.cpp:133-186). */
+POCKET_TTS_API void* ptts_state_new(PocketTTSHandle handle, int batch);
+POCKET_TTS_API void ptts_state_free(PocketTTSHandle handle, void* state);
+POCKET_TTS_API int ptts_state_reset(PocketTTSHandle handle, void* state);
+
+/* flow_lm_main, prefill shape: sequence empty, text_embeddings = emb[rows][d_model] for one utterance
+ * (src/pocket_tts.cpp:572,575). */
+POCKET_TTS_API int ptts_lm_prefill(PocketTTSHandle handle, void* state, int slot, const float* emb, int rows);
+
+/* flow_lm_main, decode shape: sequence[batch][latent_dim] (NaN row = BOS), empty text
+ * -> cond[batch][d_model], eos[batch]                               (src/pocket_tts.cpp:591-593). */
+POCKET_TTS_API int ptts_lm_step(PocketTTSHandle handle, void* state, const float* sequence, float* cond, float* eos);
+
+/* flow_lm_flow iterated lsd_steps times with the Euler update, fused on the GPU:
+ * cond[rows][d_model], x0[rows][latent_dim] -> x[rows][latent_dim]  (src/pocket_tts.cpp:414-451, 615-622). */
+POCKET_TTS_API int ptts_flow_euler(PocketTTSHandle handle, const float* cond, const float* x0, int rows, float* x);
+
+/* mimi_decoder on one chunk: latents[batch][n][latent_dim], n <= 15 -> audio[batch][n*samples_per_frame]
+ * with the state carried in `state`                                 (src/pocket_tts.cpp:463-543). */
+POCKET_TTS_API int ptts_mimi_decode(PocketTTSHandle handle, void* state, const float* latents, int n, float* audio);
+
+/* mimi_encoder: audio[samples] at 24 kHz -> out[frames][d_model]; returns frames (rows written <= cap_frames)
+ * or -1                                                             (src/pocket_tts.cpp:261-291). */
+POCKET_TTS_API int ptts_mimi_encode(PocketTTSHandle handle, const float* audio, int samples, float* out, int cap_frames);
+
+/* Benchmark support: HIP-event timing of the three per-frame phases on the engine's stream.
+ * times_ms[0..2] = LM step, flow head, decoder chunk totals; calls[0..2] = launches of each. */
+POCKET_TTS_API int ptts_phase_timing(PocketTTSHandle handle, int enable);
+POCKET_TTS_API int ptts_phase_times(PocketTTSHandle handle, double* times_ms, long* calls);
+/* bytes[0..3] = GEMM weight bytes (compute precision) of the LM, the flow head, the decoder, the encoder */
+POCKET_TTS_API int ptts_weight_bytes(PocketTTSHandle handle, unsigned long long* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* POCKET_TTS_AMD_H */

@@ -1,0 +1,666 @@
+// Model upload, per-batch state and the forward passes of the five networks on one MI355X.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace ptts {
+
+// ------------------------------------------------------------------------------------------ Model
+
+namespace {
+
+uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);  // keep NaN a NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return static_cast<uint16_t>(u >> 16);
+}
+
+bool ends_with(const std::string& s, const std::string& suf) {
+    return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+// GEMM operands get a low-precision copy; tensors consumed by the scalar kernels stay f32 only.
+bool is_gemm_weight(const std::string& name) {
+    if (!ends_with(name, ".w")) return false;
+    return name != "dec.up.w" && name != "dec.final.w" && name != "enc.conv0.w" && name != "lm.eos.w";
+}
+
+size_t align256(size_t n) { return (n + 255) & ~static_cast<size_t>(255); }
+
+}  // namespace
+
+Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec) {
+    const Spec& s = spec_;
+    if (s.d_model != s.lm_heads * 64 || s.mimi_dim != s.mimi_heads * 64)
+        throw std::runtime_error("model: attention head dimension must be 64");
+    if (s.flow_dim % 64 || s.latent % 32) throw std::runtime_error("model: flow_dim must be a multiple of 64 and latent_dim of 32");
+    // names in a deterministic order
+    std::vector<std::string> names;
+    {
+        // Pack exposes lookup only; rebuild the list from the known naming scheme by probing.
+        auto add = [&](const std::string& n) { if (pack.has(n)) names.push_back(n); else throw std::runtime_error("model: pack lacks " + n); };
+        add("text.embed"); add("lm.bos_emb"); add("lm.in_proj.w");
+        for (int i = 0; i < s.lm_layers; ++i) {
+            std::string p = "lm.l" + std::to_string(i) + ".";
+            for (const char* t : {"ln1.g", "ln1.b", "qkv.w", "out.w", "ln2.g", "ln2.b", "ff1.w", "ff2.w"}) add(p + t);
+        }
+        for (const char* t : {"lm.out_norm.g", "lm.out_norm.b", "lm.eos.w", "lm.eos.b", "flow.in_proj.w", "flow.in_proj.b"}) add(t);
+        for (int j = 0; j < 2; ++j) {
+            std::string p = "flow.time" + std::to_string(j) + ".";
+            for (const char* t : {"l1.w", "l1.b", "l2.w", "l2.b"}) add(p + t);
+        }
+        add("flow.cond.w"); add("flow.cond.b");
+        for (int i = 0; i < s.flow_blocks; ++i) {
+            std::string p = "flow.b" + std::to_string(i) + ".";
+            for (const char* t : {"ada.w", "ada.b", "ln.g", "ln.b", "fc1.w", "fc1.b", "fc2.w", "fc2.b"}) add(p + t);
+        }
+        for (const char* t : {"flow.final.ada.w", "flow.final.ada.b", "flow.final.lin.w", "flow.final.lin.b", "mimi.emb_mean", "mimi.emb_std",
+                              "dec.in_proj.w", "dec.up.w"}) add(t);
+        auto tf = [&](const std::string& pre) {
+            for (int i = 0; i < s.mimi_layers; ++i) {
+                std::string p = pre + ".t" + std::to_string(i) + ".";
+                for (const char* t : {"ln1.g", "ln1.b", "qkv.w", "out.w", "ls1", "ln2.g", "ln2.b", "ff1.w", "ff2.w", "ls2"}) add(p + t);
+            }
+        };
+        tf("dec");
+        add("dec.conv0.w"); add("dec.conv0.b");
+        for (int i = 0; i < 3; ++i) {
+            std::string p = "dec.s" + std::to_string(i) + ".";
+            for (const char* t : {"up.w", "up.b", "res.c1.w", "res.c1.b", "res.c2.w", "res.c2.b"}) add(p + t);
+        }
+        add("dec.final.w"); add("dec.final.b"); add("enc.conv0.w"); add("enc.conv0.b");
+        for (int i = 0; i < 3; ++i) {
+            std::string p = "enc.s" + std::to_string(i) + ".";
+            for (const char* t : {"res.c1.w", "res.c1.b", "res.c2.w", "res.c2.b", "down.w", "down.b"}) add(p + t);
+        }
+        add("enc.final.w"); add("enc.final.b");
+        tf("enc");
+        add("enc.down.w"); add("enc.spk_proj.w");
+    }
+    // layout: f32 blob holds everything; low-precision blob holds GEMM weights as bf16
+    size_t f32_bytes = 0, lp_bytes = 0;
+    for (auto& n : names) {
+        const HostTensor& t = pack.get(n);
+        Entry e;
+        e.shape = t.shape;
+        e.off_f32 = f32_bytes;
+        f32_bytes += align256(t.numel() * 4);
+        if (prec_ == Precision::BF16 && is_gemm_weight(n)) {
+            e.has_lp = true;
+            e.off_lp = lp_bytes;
+            lp_bytes += align256(t.numel() * 2);
+        }
+        entries_[n] = e;
+    }
+    // derived: stacked adaLN weights and bias
+    const int C = s.flow_dim;
+    mod_width = s.flow_blocks * 3 * C + 2 * C;
+    const size_t ada_w_elems = static_cast<size_t>(mod_width) * C;
+    size_t ada_off_f32 = f32_bytes;
+    f32_bytes += align256(ada_w_elems * 4);
+    size_t ada_b_off = f32_bytes;
+    f32_bytes += align256(static_cast<size_t>(mod_width) * 4);
+    size_t ada_off_lp = lp_bytes;
+    if (prec_ == Precision::BF16) lp_bytes += align256(ada_w_elems * 2);
+
+    std::vector<unsigned char> host(f32_bytes, 0);
+    for (auto& n : names) {
+        const HostTensor& t = pack.get(n);
+        std::memcpy(host.data() + entries_[n].off_f32, t.data, t.numel() * 4);
+    }
+    {
+        float* aw = reinterpret_cast<float*>(host.data() + ada_off_f32);
+        float* ab = reinterpret_cast<float*>(host.data() + ada_b_off);
+        size_t row = 0;
+        for (int i = 0; i <= s.flow_blocks; ++i) {
+            std::string p = i < s.flow_blocks ? "flow.b" + std::to_string(i) + ".ada" : "flow.final.ada";
+            const HostTensor& w = pack.get(p + ".w");
+            const HostTensor& b = pack.get(p + ".b");
+            std::memcpy(aw + row * C, w.data, w.numel() * 4);
+            std::memcpy(ab + row, b.data, b.numel() * 4);
+            row += static_cast<size_t>(w.shape[0]);
+        }
+    }
+    blob_f32_.alloc(f32_bytes);
+    PTTS_HIP(hipMemcpy(blob_f32_.p, host.data(), f32_bytes, hipMemcpyHostToDevice));
+    if (prec_ == Precision::BF16) {
+        std::vector<uint16_t> lp(lp_bytes / 2, 0);
+        auto conv = [&](size_t off_lp, const float* src, size_t n) {
+            uint16_t* d = lp.data() + off_lp / 2;
+            for (size_t i = 0; i < n; ++i) d[i] = f32_to_bf16(src[i]);
+        };
+        for (auto& n : names)
+            if (entries_[n].has_lp) conv(entries_[n].off_lp, pack.get(n).data, pack.get(n).numel());
+        conv(ada_off_lp, reinterpret_cast<const float*>(host.data() + ada_off_f32), ada_w_elems);
+        blob_lp_.alloc(lp_bytes);
+        PTTS_HIP(hipMemcpy(blob_lp_.p, lp.data(), lp_bytes, hipMemcpyHostToDevice));
+        ada_all.p = static_cast<unsigned char*>(blob_lp_.p) + ada_off_lp;
+        ada_all.wtype = W_BF16;
+    } else {
+        ada_all.p = static_cast<unsigned char*>(blob_f32_.p) + ada_off_f32;
+        ada_all.wtype = W_F32;
+    }
+    ada_all.N = mod_width;
+    ada_all.K = C;
+    ada_all_b = reinterpret_cast<const float*>(static_cast<unsigned char*>(blob_f32_.p) + ada_b_off);
+
+    // per-block pointer tables for the fused flow head
+    const int nb = s.flow_blocks;
+    std::vector<const void*> tab(static_cast<size_t>(6) * nb);
+    for (int i = 0; i < nb; ++i) {
+        std::string p = "flow.b" + std::to_string(i) + ".";
+        tab[0 * nb + i] = w(p + "fc1.w").p;
+        tab[1 * nb + i] = w(p + "fc2.w").p;
+        tab[2 * nb + i] = f(p + "fc1.b");
+        tab[3 * nb + i] = f(p + "fc2.b");
+        tab[4 * nb + i] = f(p + "ln.g");
+        tab[5 * nb + i] = f(p + "ln.b");
+    }
+    derived_.alloc(tab.size() * sizeof(void*));
+    PTTS_HIP(hipMemcpy(derived_.p, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice));
+    auto base = static_cast<const void* const*>(derived_.p);
+    d_w_fc1 = base + 0 * nb;
+    d_w_fc2 = base + 1 * nb;
+    d_b_fc1 = reinterpret_cast<const float* const*>(base + 2 * nb);
+    d_b_fc2 = reinterpret_cast<const float* const*>(base + 3 * nb);
+    d_ln_g = reinterpret_cast<const float* const*>(base + 4 * nb);
+    d_ln_b = reinterpret_cast<const float* const*>(base + 5 * nb);
+}
+
+const float* Model::f(const std::string& name) const {
+    auto it = entries_.find(name);
+    if (it == entries_.end()) throw std::runtime_error("model: unknown tensor " + name);
+    return reinterpret_cast<const float*>(static_cast<const unsigned char*>(blob_f32_.p) + it->second.off_f32);
+}
+
+DevWeight Model::w(const std::string& name) const {
+    auto it = entries_.find(name);
+    if (it == entries_.end()) throw std::runtime_error("model: unknown tensor " + name);
+    const Entry& e = it->second;
+    if (e.shape.size() != 2) throw std::runtime_error("model: " + name + " is not a matrix");
+    DevWeight d;
+    d.N = static_cast<int>(e.shape[0]);
+    d.K = static_cast<int>(e.shape[1]);
+    if (e.has_lp) {
+        d.p = static_cast<const unsigned char*>(blob_lp_.p) + e.off_lp;
+        d.wtype = W_BF16;
+    } else {
+        d.p = static_cast<const unsigned char*>(blob_f32_.p) + e.off_f32;
+        d.wtype = W_F32;
+    }
+    return d;
+}
+
+size_t Model::gemm_weight_bytes(const std::string& prefix) const {
+    size_t n = 0;
+    for (auto& kv : entries_) {
+        if (kv.first.compare(0, prefix.size(), prefix) != 0 || !is_gemm_weight(kv.first)) continue;
+        size_t el = 1;
+        for (auto d : kv.second.shape) el *= static_cast<size_t>(d);
+        n += el * (kv.second.has_lp ? 2 : 4);
+    }
+    return n;
+}
+
+std::vector<TfLayer> Model::tf_layers(const std::string& prefix, int layers, bool has_ls) const {
+    std::vector<TfLayer> out;
+    for (int i = 0; i < layers; ++i) {
+        std::string p = prefix + std::to_string(i) + ".";
+        TfLayer l;
+        l.ln1g = f(p + "ln1.g"); l.ln1b = f(p + "ln1.b"); l.ln2g = f(p + "ln2.g"); l.ln2b = f(p + "ln2.b");
+        l.ls1 = has_ls ? f(p + "ls1") : nullptr;
+        l.ls2 = has_ls ? f(p + "ls2") : nullptr;
+        l.qkv = w(p + "qkv.w"); l.out = w(p + "out.w"); l.ff1 = w(p + "ff1.w"); l.ff2 = w(p + "ff2.w");
+        out.push_back(l);
+    }
+    return out;
+}
+
+// cos/sin of pos * max_period^(-2i/64) in double, rounded once to f32: identical inputs to the
+// rotation on every implementation that builds the table the same way.
+void Model::build_rope_tables(int lm_len, int mimi_len) {
+    const int half = 32;
+    auto fill = [&](std::vector<float>& c, std::vector<float>& s, int len, int max_period) {
+        c.resize(static_cast<size_t>(len) * half);
+        s.resize(static_cast<size_t>(len) * half);
+        for (int i = 0; i < half; ++i) {
+            double freq = std::exp(-std::log(static_cast<double>(max_period)) * 2.0 * i / 64.0);
+            for (int p = 0; p < len; ++p) {
+                double a = static_cast<double>(p) * freq;
+                c[static_cast<size_t>(p) * half + i] = static_cast<float>(std::cos(a));
+                s[static_cast<size_t>(p) * half + i] = static_cast<float>(std::sin(a));
+            }
+        }
+    };
+    std::vector<float> lc, ls, mc, ms;
+    fill(lc, ls, lm_len, spec_.lm_max_period);
+    fill(mc, ms, mimi_len, spec_.mimi_max_period);
+    size_t lb = align256(lc.size() * 4), mb = align256(mc.size() * 4);
+    rope_.alloc(2 * lb + 2 * mb);
+    auto* base = static_cast<unsigned char*>(rope_.p);
+    PTTS_HIP(hipMemcpy(base, lc.data(), lc.size() * 4, hipMemcpyHostToDevice));
+    PTTS_HIP(hipMemcpy(base + lb, ls.data(), ls.size() * 4, hipMemcpyHostToDevice));
+    PTTS_HIP(hipMemcpy(base + 2 * lb, mc.data(), mc.size() * 4, hipMemcpyHostToDevice));
+    PTTS_HIP(hipMemcpy(base + 2 * lb + mb, ms.data(), ms.size() * 4, hipMemcpyHostToDevice));
+    lm_cos = reinterpret_cast<const float*>(base);
+    lm_sin = reinterpret_cast<const float*>(base + lb);
+    mimi_cos = reinterpret_cast<const float*>(base + 2 * lb);
+    mimi_sin = reinterpret_cast<const float*>(base + 2 * lb + mb);
+    lm_tab_len = lm_len;
+    mimi_tab_len = mimi_len;
+}
+
+// ------------------------------------------------------------------------------------------ Batch
+
+static constexpr int kDecChunk = 15;  // frames per decoder call, /root/reference/src/pocket_tts.cpp:461
+
+Batch::Batch(Engine& e, int B_) : B(B_) {
+    const Spec& s = e.spec();
+    const EngineOptions& o = e.options();
+    const int D = s.d_model, M = s.mimi_dim, L = s.latent, U = s.upsample;
+    lm_cap = 64 + o.max_text_tokens + o.max_frames + 8;
+    lm_cap = (lm_cap + 63) / 64 * 64;
+    dec_cap = s.mimi_context + kDecChunk * U + 8;
+    const int T0 = kDecChunk * U;
+    max_rows = std::max(std::max(B, 256), B * T0);
+    lm_k.alloc(static_cast<size_t>(s.lm_layers) * B * lm_cap * D * 4);
+    lm_v.alloc(static_cast<size_t>(s.lm_layers) * B * lm_cap * D * 4);
+    lm_pos.alloc(static_cast<size_t>(B) * 4);
+    lm_pos_host.assign(B, 0);
+    dec_k.alloc(static_cast<size_t>(s.mimi_layers) * B * dec_cap * M * 4);
+    dec_v.alloc(static_cast<size_t>(s.mimi_layers) * B * dec_cap * M * 4);
+    dec_pos.alloc(static_cast<size_t>(B) * 4);
+    const int dmax = std::max(D, M), fmax = std::max(s.lm_ffn, s.mimi_ffn);
+    // transformer scratch: LM passes use at most max(B, 256) rows of width D, decoder passes B*T0 rows of width M
+    size_t rows_lm = std::max(B, 256), rows_dec = static_cast<size_t>(B) * T0;
+    size_t xe = std::max(rows_lm * D, rows_dec * M);
+    x.alloc(xe * 4); h.alloc(xe * 4); q.alloc(xe * 4); att.alloc(xe * 4);
+    qkv.alloc(xe * 3 * 4);
+    ff.alloc(std::max(rows_lm * s.lm_ffn, rows_dec * s.mimi_ffn) * 4);
+    (void)dmax; (void)fmax;
+    seq_in.alloc(static_cast<size_t>(B) * L * 4);
+    cond.alloc(static_cast<size_t>(B) * D * 4);
+    eos.alloc(static_cast<size_t>(B) * 4);
+    x0.alloc(static_cast<size_t>(B) * L * 4);
+    xcur.alloc(static_cast<size_t>(B) * L * 4);
+    latents.alloc(static_cast<size_t>(B) * o.max_frames * L * 4);
+    ids.alloc(static_cast<size_t>(std::max(o.max_text_tokens, 1)) * 8);
+    const int C = s.flow_dim;
+    cemb.alloc(static_cast<size_t>(B) * C * 4);
+    ymod.alloc(static_cast<size_t>(o.lsd_steps) * B * C * 4);
+    mods.alloc(static_cast<size_t>(o.lsd_steps) * B * e.model().mod_width * 4);
+    // decoder activations
+    zbuf.alloc(static_cast<size_t>(B) * kDecChunk * L * 4);
+    qbuf.alloc(static_cast<size_t>(B) * (1 + kDecChunk) * M * 4);
+    ybuf.alloc(static_cast<size_t>(B) * (s.kernel - 1 + T0) * M * 4);
+    int c = 8 * s.n_filters;
+    e0buf.alloc(static_cast<size_t>(B) * (1 + T0) * c * 4);
+    int T = T0;
+    for (int i = 0; i < 3; ++i) {
+        int co = c / 2;
+        T *= s.ratios[i];
+        int hn = i < 2 ? 1 : s.last_kernel - 1;
+        ubuf[i].alloc(static_cast<size_t>(B) * T * co * 4);
+        uebuf[i].alloc(static_cast<size_t>(B) * (s.res_kernel - 1 + T) * co * 4);
+        h1buf[i].alloc(static_cast<size_t>(B) * T * (co / 2) * 4);
+        ebuf[i].alloc(static_cast<size_t>(B) * (hn + T) * co * 4);
+        c = co;
+    }
+    audio.alloc(static_cast<size_t>(B) * kDecChunk * s.frame_size() * 4);
+    PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_eos), static_cast<size_t>(B) * 4));
+    PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_x0), static_cast<size_t>(B) * L * 4));
+    reset(e.stream());
+}
+
+Batch::~Batch() {
+    if (h_eos) (void)hipHostFree(h_eos);
+    if (h_x0) (void)hipHostFree(h_x0);
+}
+
+// Zero every recurrent state: the reference zero-initialises all state_* inputs (src/pocket_tts.cpp:133-186).
+void Batch::reset(hipStream_t s) {
+    PTTS_HIP(hipMemsetAsync(lm_pos.p, 0, lm_pos.bytes, s));
+    PTTS_HIP(hipMemsetAsync(dec_pos.p, 0, dec_pos.bytes, s));
+    std::fill(lm_pos_host.begin(), lm_pos_host.end(), 0);
+    dec_pos_host = 0;
+    for (DevBuf* b : {&qbuf, &ybuf, &e0buf, &uebuf[0], &uebuf[1], &uebuf[2], &ebuf[0], &ebuf[1], &ebuf[2]})
+        PTTS_HIP(hipMemsetAsync(b->p, 0, b->bytes, s));
+    PTTS_HIP(hipMemsetAsync(x0.p, 0, x0.bytes, s));
+}
+
+// ------------------------------------------------------------------------------------------ Engine
+
+namespace {
+float silu_h(float v) { return v / (1.0f + std::exp(-v)); }
+}  // namespace
+
+Engine::Engine(const EngineOptions& opt) : opt_(opt) {
+    if (opt_.lsd_steps <= 0 || opt_.max_frames <= 0) throw std::runtime_error("engine: lsd_steps and max_frames must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        throw std::runtime_error("no HIP device available: the MI355X engine has no CPU fallback");
+    if (opt_.device < 0 || opt_.device >= ndev) throw std::runtime_error("engine: device ordinal out of range");
+    PTTS_HIP(hipSetDevice(opt_.device));
+    PTTS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    Pack pack(opt_.pack_path);
+    model_ = std::make_unique<Model>(pack, opt_.precision);
+    const Spec& s = model_->spec();
+    const int lm_len = 64 + opt_.max_text_tokens + opt_.max_frames + 8 + 64;
+    const int mimi_len = std::max((opt_.max_frames + kDecChunk) * s.upsample + 64, 2048);
+    model_->build_rope_tables(lm_len, mimi_len);
+    if (opt_.has_seed) rng_.seed(static_cast<uint32_t>(opt_.seed));
+    else rng_.seed(std::random_device{}());
+
+    // averaged time embeddings of the fixed Euler grid s_j = j/N, t_j = s_j + 1/N (src/pocket_tts.cpp:122-130)
+    const int C = s.flow_dim, Q = s.flow_freq, half = Q / 2, N = opt_.lsd_steps;
+    std::vector<float> te(static_cast<size_t>(N) * C, 0.f), fe(Q), hid(C), out(C);
+    const float dt = 1.0f / static_cast<float>(N);
+    for (int j = 0; j < N; ++j) {
+        const float sv = static_cast<float>(j) / static_cast<float>(N);
+        const float tv = sv + dt;
+        for (int which = 0; which < 2; ++which) {
+            const float val = which == 0 ? sv : tv;
+            std::string p = "flow.time" + std::to_string(which) + ".";
+            const HostTensor &w1 = pack.get(p + "l1.w"), &b1 = pack.get(p + "l1.b"), &w2 = pack.get(p + "l2.w"), &b2 = pack.get(p + "l2.b");
+            for (int i = 0; i < half; ++i) {
+                double freq = std::exp(-std::log(static_cast<double>(s.flow_max_period)) * i / half);
+                double a = static_cast<double>(val) * freq;
+                fe[i] = static_cast<float>(std::cos(a));
+                fe[half + i] = static_cast<float>(std::sin(a));
+            }
+            for (int n = 0; n < C; ++n) {
+                float acc = 0.f;
+                for (int k = 0; k < Q; ++k) acc += fe[k] * w1.data[static_cast<size_t>(n) * Q + k];
+                hid[n] = silu_h(acc + b1.data[n]);
+            }
+            for (int n = 0; n < C; ++n) {
+                float acc = 0.f;
+                for (int k = 0; k < C; ++k) acc += hid[k] * w2.data[static_cast<size_t>(n) * C + k];
+                out[n] = acc + b2.data[n];
+            }
+            for (int n = 0; n < C; ++n) te[static_cast<size_t>(j) * C + n] += out[n];
+        }
+        for (int n = 0; n < C; ++n) te[static_cast<size_t>(j) * C + n] *= 0.5f;
+    }
+    // resolve every per-frame device pointer once
+    {
+        const Model& m = *model_;
+        hd_.lm = m.tf_layers("lm.l", s.lm_layers, false);
+        hd_.dec = m.tf_layers("dec.t", s.mimi_layers, true);
+        hd_.enc = m.tf_layers("enc.t", s.mimi_layers, true);
+        hd_.lm_in = m.w("lm.in_proj.w"); hd_.flow_cond = m.w("flow.cond.w"); hd_.flow_in = m.w("flow.in_proj.w");
+        hd_.flow_out = m.w("flow.final.lin.w"); hd_.dec_in = m.w("dec.in_proj.w"); hd_.dec_conv0 = m.w("dec.conv0.w");
+        hd_.bos = m.f("lm.bos_emb"); hd_.out_g = m.f("lm.out_norm.g"); hd_.out_b = m.f("lm.out_norm.b");
+        hd_.eos_w = m.f("lm.eos.w"); hd_.eos_b = m.f("lm.eos.b"); hd_.flow_cond_b = m.f("flow.cond.b");
+        hd_.flow_in_b = m.f("flow.in_proj.b"); hd_.flow_out_b = m.f("flow.final.lin.b");
+        hd_.emb_std = m.f("mimi.emb_std"); hd_.emb_mean = m.f("mimi.emb_mean"); hd_.dec_up_w = m.f("dec.up.w");
+        hd_.dec_conv0_b = m.f("dec.conv0.b"); hd_.dec_final_w = m.f("dec.final.w"); hd_.dec_final_b = m.f("dec.final.b");
+        hd_.enc_conv0_w = m.f("enc.conv0.w"); hd_.enc_conv0_b = m.f("enc.conv0.b");
+        hd_.enc_final = m.w("enc.final.w"); hd_.enc_final_b = m.f("enc.final.b");
+        hd_.enc_ds = m.w("enc.down.w"); hd_.enc_spk = m.w("enc.spk_proj.w"); hd_.text_embed = m.f("text.embed");
+        for (int i = 0; i < 3; ++i) {
+            std::string p = "dec.s" + std::to_string(i) + ".", q = "enc.s" + std::to_string(i) + ".";
+            hd_.dec_up[i] = m.w(p + "up.w"); hd_.dec_c1[i] = m.w(p + "res.c1.w"); hd_.dec_c2[i] = m.w(p + "res.c2.w");
+            hd_.dec_up_b[i] = m.f(p + "up.b"); hd_.dec_c1_b[i] = m.f(p + "res.c1.b"); hd_.dec_c2_b[i] = m.f(p + "res.c2.b");
+            hd_.enc_c1[i] = m.w(q + "res.c1.w"); hd_.enc_c2[i] = m.w(q + "res.c2.w"); hd_.enc_down[i] = m.w(q + "down.w");
+            hd_.enc_c1_b[i] = m.f(q + "res.c1.b"); hd_.enc_c2_b[i] = m.f(q + "res.c2.b"); hd_.enc_down_b[i] = m.f(q + "down.b");
+        }
+    }
+    flow_te_.alloc(te.size() * 4);
+    PTTS_HIP(hipMemcpy(flow_te_.p, te.data(), te.size() * 4, hipMemcpyHostToDevice));
+    PTTS_HIP(hipEventCreate(&ev_[0]));
+    PTTS_HIP(hipEventCreate(&ev_[1]));
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(opt_.device);
+    (void)hipStreamSynchronize(stream_);
+    batch_pool_.clear();
+    for (auto& pe : pending_events_) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
+    if (ev_[0]) (void)hipEventDestroy(ev_[0]);
+    if (ev_[1]) (void)hipEventDestroy(ev_[1]);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::enable_phase_timing(bool on) { timing_ = on; times_ = PhaseTimes(); }
+
+void Engine::phase_begin(int which) {
+    if (!timing_) return;
+    hipEvent_t a, b;
+    PTTS_HIP(hipEventCreate(&a));
+    PTTS_HIP(hipEventCreate(&b));
+    PTTS_HIP(hipEventRecord(a, stream_));
+    pending_events_.push_back({which, {a, b}});
+}
+
+void Engine::phase_end(int which) {
+    if (!timing_) return;
+    for (auto it = pending_events_.rbegin(); it != pending_events_.rend(); ++it)
+        if (it->first == which) { PTTS_HIP(hipEventRecord(it->second.second, stream_)); return; }
+}
+
+Engine::PhaseTimes Engine::phase_times() {
+    PTTS_HIP(hipStreamSynchronize(stream_));
+    for (auto& pe : pending_events_) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) {
+            if (pe.first == 0) { times_.lm_ms += ms; times_.lm_calls++; }
+            else if (pe.first == 1) { times_.flow_ms += ms; times_.flow_calls++; }
+            else { times_.dec_ms += ms; times_.dec_calls++; }
+        }
+        (void)hipEventDestroy(pe.second.first);
+        (void)hipEventDestroy(pe.second.second);
+    }
+    pending_events_.clear();
+    return times_;
+}
+
+Batch* Engine::batch_new(int B) {
+    PTTS_HIP(hipSetDevice(opt_.device));
+    return new Batch(*this, B);
+}
+void Engine::batch_free(Batch* b) { delete b; }
+void Engine::batch_reset(Batch* b) { b->reset(stream_); }
+
+Batch* Engine::acquire_batch(int B) {
+    auto it = batch_pool_.find(B);
+    if (it == batch_pool_.end()) it = batch_pool_.emplace(B, std::make_unique<Batch>(*this, B)).first;
+    else it->second->reset(stream_);
+    return it->second.get();
+}
+
+// One pre-norm transformer stack over M = nb * rpb new rows X[M][d] (in place), appending to the
+// per-slot KV cache.  If last_out is given, the final residual sum is written there (batched-row
+// mapping) instead of X, which is how the decoder hands its result to the first SEANet convolution's
+// history buffer without a copy.
+void Engine::transformer(const std::vector<TfLayer>& layers, float* kc, float* vc, long long layer_stride, int cap,
+                         const int* pos_dev, int slot0, int nb, int rpb, float* X, int d, int heads, int ffn, float eps,
+                         int window, const float* cos_tab, const float* sin_tab, int tab_len, const TfScratch& b, float* last_out,
+                         long long last_bs, int last_ld) {
+    const int M = nb * rpb;
+    for (size_t l = 0; l < layers.size(); ++l) {
+        const TfLayer& w = layers[l];
+        LayerNormArgs ln;
+        ln.X = X; ln.ldx = d; ln.Y = b.h; ln.ldy = d; ln.M = M; ln.D = d; ln.g = w.ln1g; ln.b = w.ln1b; ln.eps = eps;
+        launch_layernorm(ln, stream_);
+        GemmArgs g;
+        g.A = b.h; g.lda = d; g.W = w.qkv.p; g.wtype = w.qkv.wtype; g.C = b.qkv; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d;
+        launch_gemm(g, stream_);
+        RopeAppendArgs r;
+        r.qkv = b.qkv; r.q_out = b.q; r.kcache = kc + l * layer_stride; r.vcache = vc + l * layer_stride;
+        r.pos = pos_dev; r.slot0 = slot0; r.rpb = rpb; r.M = M; r.d = d; r.heads = heads; r.cap = cap;
+        r.cos_tab = cos_tab; r.sin_tab = sin_tab; r.tab_len = tab_len;
+        launch_rope_append(r, stream_);
+        AttentionArgs at;
+        at.q = b.q; at.out = b.att; at.kcache = r.kcache; at.vcache = r.vcache; at.pos = pos_dev; at.slot0 = slot0; at.rpb = rpb;
+        at.M = M; at.d = d; at.heads = heads; at.cap = cap; at.window = window;
+        launch_attention(at, stream_);
+        GemmArgs o;
+        o.A = b.att; o.lda = d; o.W = w.out.p; o.wtype = w.out.wtype; o.C = X; o.ldc = d; o.R = X; o.ldr = d; o.colscale = w.ls1;
+        o.M = M; o.N = d; o.K = d;
+        launch_gemm(o, stream_);
+        ln.g = w.ln2g; ln.b = w.ln2b;
+        launch_layernorm(ln, stream_);
+        GemmArgs f1;
+        f1.A = b.h; f1.lda = d; f1.W = w.ff1.p; f1.wtype = w.ff1.wtype; f1.C = b.ff; f1.ldc = ffn; f1.act_pre = ACT_GELU;
+        f1.M = M; f1.N = ffn; f1.K = d;
+        launch_gemm(f1, stream_);
+        GemmArgs f2;
+        f2.A = b.ff; f2.lda = ffn; f2.W = w.ff2.p; f2.wtype = w.ff2.wtype; f2.R = X; f2.ldr = d; f2.colscale = w.ls2;
+        f2.M = M; f2.N = d; f2.K = ffn;
+        if (last_out && l + 1 == layers.size()) {
+            f2.C = last_out; f2.c_bs = last_bs; f2.ldc = last_ld; f2.rpb = rpb;
+            f2.r_bs = (long long)rpb * d; f2.a_bs = (long long)rpb * ffn;
+        }
+        else { f2.C = X; f2.ldc = d; }
+        launch_gemm(f2, stream_);
+    }
+}
+
+void Engine::lm_rows(Batch& b, int slot0, int nb, int rpb, float* X) {
+    const Spec& s = spec();
+    for (int i = 0; i < nb; ++i)
+        if (b.lm_pos_host[slot0 + i] + rpb > b.lm_cap)
+            throw std::runtime_error("LM context exceeds the KV-cache capacity (voice + text + frames too long)");
+    const auto& layers = hd_.lm;
+    const long long layer_stride = static_cast<long long>(b.B) * b.lm_cap * s.d_model;
+    transformer(layers, b.lm_k.f(), b.lm_v.f(), layer_stride, b.lm_cap, b.lm_pos.as<int>() + slot0, slot0, nb, rpb, X, s.d_model,
+                s.lm_heads, s.lm_ffn, s.lm_eps, 0, model_->lm_cos, model_->lm_sin, model_->lm_tab_len, b.scratch(), nullptr, 0, 0);
+    launch_advance_pos(b.lm_pos.as<int>() + slot0, nb, rpb, stream_);
+    for (int i = 0; i < nb; ++i) b.lm_pos_host[slot0 + i] += rpb;
+}
+
+// sequence[B][latent] (NaN = BOS) -> conditioning[B][d_model], eos[B]   (src/pocket_tts.cpp:323-411, decode shape)
+void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev) {
+    const Spec& s = spec();
+    phase_begin(0);
+    launch_prep_latent(seq_dev, b.seq_in.f(), b.B, s.latent, 0, hd_.bos, nullptr, stream_);
+    const DevWeight& win = hd_.lm_in;
+    GemmArgs g;
+    g.A = b.seq_in.f(); g.lda = s.latent; g.W = win.p; g.wtype = win.wtype; g.C = b.x.f(); g.ldc = s.d_model;
+    g.M = b.B; g.N = s.d_model; g.K = s.latent;
+    launch_gemm(g, stream_);
+    lm_rows(b, 0, b.B, 1, b.x.f());
+    LayerNormArgs ln;
+    ln.X = b.x.f(); ln.ldx = s.d_model; ln.Y = cond_dev; ln.ldy = s.d_model; ln.M = b.B; ln.D = s.d_model;
+    ln.g = hd_.out_g; ln.b = hd_.out_b; ln.eps = s.lm_eps;
+    launch_layernorm(ln, stream_);
+    launch_rowdot(cond_dev, s.d_model, b.B, s.d_model, hd_.eos_w, hd_.eos_b, eos_dev, stream_);
+    phase_end(0);
+}
+
+// lsd_steps Euler iterations for B rows: 3 small launches for the adaLN vectors, then the fused head.
+void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B) {
+    const Spec& s = spec();
+    const int C = s.flow_dim, N = opt_.lsd_steps;
+    phase_begin(1);
+    const DevWeight& wc = hd_.flow_cond;
+    GemmArgs g;
+    g.A = cond_dev; g.lda = s.d_model; g.W = wc.p; g.wtype = wc.wtype; g.C = b.cemb.f(); g.ldc = C; g.bias = hd_.flow_cond_b;
+    g.M = B; g.N = C; g.K = s.d_model;
+    launch_gemm(g, stream_);
+    launch_flow_mod_input(flow_te_.f(), b.cemb.f(), b.ymod.f(), N, B, C, stream_);
+    GemmArgs m;
+    m.A = b.ymod.f(); m.lda = C; m.W = model_->ada_all.p; m.wtype = model_->ada_all.wtype; m.C = b.mods.f(); m.ldc = model_->mod_width;
+    m.bias = model_->ada_all_b; m.M = N * B; m.N = model_->mod_width; m.K = C;
+    launch_gemm(m, stream_);
+    FlowHeadArgs fa;
+    fa.x0 = x0_dev; fa.x0_stride = x0_stride; fa.x_out = x_out_dev; fa.mods = b.mods.f(); fa.B = B; fa.L = s.latent; fa.C = C; fa.blocks = s.flow_blocks;
+    fa.steps = N; fa.mod_width = model_->mod_width;
+    const DevWeight &win = hd_.flow_in, &wout = hd_.flow_out;
+    fa.w_in = win.p; fa.b_in = hd_.flow_in_b; fa.w_out = wout.p; fa.b_out = hd_.flow_out_b;
+    fa.w_fc1 = model_->d_w_fc1; fa.w_fc2 = model_->d_w_fc2; fa.b_fc1 = model_->d_b_fc1; fa.b_fc2 = model_->d_b_fc2;
+    fa.ln_g = model_->d_ln_g; fa.ln_b = model_->d_ln_b; fa.wtype = win.wtype; fa.eps = s.flow_eps;
+    launch_flow_head(fa, stream_);
+    phase_end(1);
+}
+
+// latent rows (batched mapping: utterance b at lat_dev + b*lat_bs, n rows of `latent` floats)
+// -> audio[b][n*frame]   (src/pocket_tts.cpp:454-546 for one chunk of n <= 15 frames)
+void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs) {
+    const Spec& s = spec();
+    if (n <= 0 || n > kDecChunk) throw std::runtime_error("decoder chunk must hold 1..15 frames");
+    const int B = b.B, L = s.latent, M = s.mimi_dim, U = s.upsample;
+    const int T0 = n * U, T0max = kDecChunk * U;
+    if (b.dec_pos_host + T0 > model_->mimi_tab_len) throw std::runtime_error("decoder position exceeds the rotary table");
+    phase_begin(2);
+    // gather the chunk's latent rows and de-normalise them
+    PTTS_HIP(hipMemcpy2DAsync(b.zbuf.p, static_cast<size_t>(n) * L * 4, lat_dev, static_cast<size_t>(lat_bs) * 4,
+                              static_cast<size_t>(n) * L * 4, B, hipMemcpyDeviceToDevice, stream_));
+    launch_prep_latent(b.zbuf.f(), b.zbuf.f(), B * n, L, 1, hd_.emb_std, hd_.emb_mean, stream_);
+    const DevWeight& wi = hd_.dec_in;
+    GemmArgs g;
+    g.A = b.zbuf.f(); g.lda = L; g.W = wi.p; g.wtype = wi.wtype; g.M = B * n; g.N = M; g.K = L; g.rpb = n;
+    g.a_bs = static_cast<long long>(n) * L;
+    g.C = b.qbuf.f() + M; g.c_bs = static_cast<long long>(1 + kDecChunk) * M; g.ldc = M;
+    launch_gemm(g, stream_);
+    launch_upsample_dw(b.qbuf.f(), static_cast<long long>(1 + kDecChunk) * M, n, M, U, hd_.dec_up_w, b.x.f(), B, stream_);
+    const int H0 = s.kernel - 1;
+    const auto& layers = hd_.dec;
+    const long long ybs = static_cast<long long>(H0 + T0max) * M;
+    transformer(layers, b.dec_k.f(), b.dec_v.f(), static_cast<long long>(B) * b.dec_cap * M, b.dec_cap, b.dec_pos.as<int>(), 0, B, T0,
+                b.x.f(), M, s.mimi_heads, s.mimi_ffn, s.mimi_eps, s.mimi_context, model_->mimi_cos, model_->mimi_sin,
+                model_->mimi_tab_len, b.scratch(), b.ybuf.f() + static_cast<long long>(H0) * M, ybs, M);
+    // SEANet decoder
+    int c = 8 * s.n_filters;
+    {
+        const DevWeight& w = hd_.dec_conv0;
+        GemmArgs a;
+        a.A = b.ybuf.f(); a.a_bs = ybs; a.lda = M; a.rpb = T0; a.W = w.p; a.wtype = w.wtype; a.bias = hd_.dec_conv0_b;
+        a.M = B * T0; a.N = c; a.K = s.kernel * M;
+        a.C = b.e0buf.f() + c; a.c_bs = static_cast<long long>(1 + T0max) * c; a.ldc = c; a.c_act = ACT_ELU;
+        launch_gemm(a, stream_);
+    }
+    const float* prev = b.e0buf.f();
+    long long prev_bs = static_cast<long long>(1 + T0max) * c;
+    int T = T0, Tmax = T0max;
+    for (int i = 0; i < 3; ++i) {
+        const int r = s.ratios[i], co = c / 2, T2 = T * r, T2max = Tmax * r, rk = s.res_kernel;
+        const int hn = i < 2 ? 1 : s.last_kernel - 1;
+        const DevWeight &wu = hd_.dec_up[i], &w1 = hd_.dec_c1[i], &w2 = hd_.dec_c2[i];
+        GemmArgs up;  // transposed conv: rows = input steps, N = r * co output samples x channels
+        up.A = prev; up.a_bs = prev_bs; up.lda = c; up.rpb = T; up.W = wu.p; up.wtype = wu.wtype;
+        up.bias = hd_.dec_up_b[i]; up.bias_mod = co; up.M = B * T; up.N = r * co; up.K = 2 * c;
+        up.C = b.ubuf[i].f(); up.c_bs = static_cast<long long>(T2max) * co; up.ldc = r * co;
+        up.C2 = b.uebuf[i].f() + static_cast<long long>(rk - 1) * co; up.c2_bs = static_cast<long long>(rk - 1 + T2max) * co;
+        up.ldc2 = r * co; up.c2_act = ACT_ELU;
+        launch_gemm(up, stream_);
+        GemmArgs c1;
+        c1.A = b.uebuf[i].f(); c1.a_bs = up.c2_bs; c1.lda = co; c1.rpb = T2; c1.W = w1.p; c1.wtype = w1.wtype;
+        c1.bias = hd_.dec_c1_b[i]; c1.M = B * T2; c1.N = co / 2; c1.K = rk * co;
+        c1.C = b.h1buf[i].f(); c1.c_bs = static_cast<long long>(T2max) * (co / 2); c1.ldc = co / 2; c1.c_act = ACT_ELU;
+        launch_gemm(c1, stream_);
+        GemmArgs c2;
+        c2.A = b.h1buf[i].f(); c2.a_bs = c1.c_bs; c2.lda = co / 2; c2.rpb = T2; c2.W = w2.p; c2.wtype = w2.wtype;
+        c2.bias = hd_.dec_c2_b[i]; c2.M = B * T2; c2.N = co; c2.K = co / 2;
+        c2.R = b.ubuf[i].f(); c2.r_bs = up.c_bs; c2.ldr = co;
+        c2.C = b.ebuf[i].f() + static_cast<long long>(hn) * co; c2.c_bs = static_cast<long long>(hn + T2max) * co; c2.ldc = co;
+        c2.c_act = ACT_ELU;
+        launch_gemm(c2, stream_);
+        prev = b.ebuf[i].f(); prev_bs = c2.c_bs;
+        c = co; T = T2; Tmax = T2max;
+    }
+    launch_conv_to_mono(prev, prev_bs, T, s.last_kernel * c, c, hd_.dec_final_w, hd_.dec_final_b, audio_dev, audio_bs, B, stream_);
+    // carry the streaming histories and positions to the next chunk
+    launch_shift_history(b.qbuf.f(), static_cast<long long>(1 + kDecChunk) * M, n, 1, M, B, stream_);
+    launch_shift_history(b.ybuf.f(), ybs, T0, H0, M, B, stream_);
+    c = 8 * s.n_filters;
+    launch_shift_history(b.e0buf.f(), static_cast<long long>(1 + T0max) * c, T0, 1, c, B, stream_);
+    T = T0; Tmax = T0max;
+    for (int i = 0; i < 3; ++i) {
+        const int co = c / 2, rk = s.res_kernel, hn = i < 2 ? 1 : s.last_kernel - 1;
+        T *= s.ratios[i]; Tmax *= s.ratios[i];
+        launch_shift_history(b.uebuf[i].f(), static_cast<long long>(rk - 1 + Tmax) * co, T, rk - 1, co, B, stream_);
+        launch_shift_history(b.ebuf[i].f(), static_cast<long long>(hn + Tmax) * co, T, hn, co, B, stream_);
+        c = co;
+    }
+    launch_advance_pos(b.dec_pos.as<int>(), B, T0, stream_);
+    b.dec_pos_host += T0;
+    phase_end(2);
+}
+
+}  // namespace ptts

@@ -1,0 +1,228 @@
+// Device-side model and the batched inference engine that replaces the reference's five ONNX Runtime
+// sessions (/root/reference/src/pocket_tts.cpp:59-63, 89-113) and its per-call state plumbing
+// (:133-239).  All recurrent state (KV caches, convolution histories, positions) lives in HBM for the
+// life of a batch and is never copied to the host.
+#pragma once
+
+#include <atomic>
+#include <cstdint>
+#include <functional>
+#include <mutex>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace ptts {
+
+enum class Precision { FP32, BF16 };
+
+struct DevWeight {
+    const void* p = nullptr;
+    int wtype = W_F32;
+    int N = 0, K = 0;
+};
+
+struct TfLayer {
+    const float *ln1g, *ln1b, *ln2g, *ln2b, *ls1, *ls2;
+    DevWeight qkv, out, ff1, ff2;
+};
+
+// Weights resident on one GPU, in f32 plus (for GEMM operands) the active compute precision.
+class Model {
+public:
+    Model(const Pack& pack, Precision prec);
+    const Spec& spec() const { return spec_; }
+    Precision precision() const { return prec_; }
+    const float* f(const std::string& name) const;  // f32 tensor on device
+    DevWeight w(const std::string& name) const;     // GEMM weight [N][K] in the compute precision
+    std::vector<TfLayer> tf_layers(const std::string& prefix, int layers, bool has_ls) const;
+    size_t gemm_weight_bytes(const std::string& prefix) const;  // bytes of GEMM weights whose name starts with prefix
+
+    // derived tensors
+    DevWeight ada_all;           // stacked adaLN weights [blocks*3C + 2C][C]
+    const float* ada_all_b = nullptr;
+    int mod_width = 0;
+    const float *lm_cos = nullptr, *lm_sin = nullptr; int lm_tab_len = 0;
+    const float *mimi_cos = nullptr, *mimi_sin = nullptr; int mimi_tab_len = 0;
+    // per-block pointer tables for the fused flow head (device arrays)
+    const void* const* d_w_fc1 = nullptr; const void* const* d_w_fc2 = nullptr;
+    const float* const* d_b_fc1 = nullptr; const float* const* d_b_fc2 = nullptr;
+    const float* const* d_ln_g = nullptr; const float* const* d_ln_b = nullptr;
+
+    void build_rope_tables(int lm_len, int mimi_len);
+
+private:
+    struct Entry { size_t off_f32 = 0; size_t off_lp = 0; bool has_lp = false; std::vector<int64_t> shape; };
+    Spec spec_;
+    Precision prec_;
+    std::map<std::string, Entry> entries_;
+    DevBuf blob_f32_, blob_lp_, derived_, rope_;
+    std::vector<DevBuf> extra_;
+};
+
+struct EngineOptions {
+    std::string pack_path;
+    Precision precision = Precision::BF16;
+    int device = 0;
+    int lsd_steps = 10;
+    int max_frames = 500;
+    int frames_after_eos = 3;
+    float temperature = 0.7f;
+    int max_text_tokens = 512;
+    uint64_t seed = 0;         // 0: seed from std::random_device like the reference (src/pocket_tts.cpp:72)
+    bool has_seed = false;
+};
+
+struct Utterance {
+    std::vector<int64_t> token_ids;
+    const float* voice = nullptr;  // [voice_frames][d_model] host
+    int voice_frames = 0;
+    const float* noise = nullptr;  // optional [max_frames][latent] host start points (already scaled); overrides temperature
+};
+
+struct UtteranceResult {
+    int frames = 0;
+    std::vector<float> audio;    // frames * frame_size
+    std::vector<float> latents;  // frames * latent (filled when requested)
+    std::vector<float> eos;      // one logit per LM step run (filled when requested)
+};
+
+// Scratch rows of one transformer pass: h [M][d], qkv [M][3d], q [M][d], att [M][d], ff [M][ffn].
+struct TfScratch { float *h, *qkv, *q, *att, *ff; };
+
+// (samples, count, is_final)
+using ChunkCallback = std::function<void(const float*, int, bool)>;
+
+class Batch;
+
+class Engine {
+public:
+    explicit Engine(const EngineOptions& opt);
+    ~Engine();
+    const Spec& spec() const { return model_->spec(); }
+    const EngineOptions& options() const { return opt_; }
+    const Model& model() const { return *model_; }
+    hipStream_t stream() const { return stream_; }
+
+    // ---- whole-path entry points (lock-step batch of independent utterances) ----
+    // Offline: /root/reference/src/pocket_tts.cpp:548-657 for every utterance of the batch.
+    void generate(const std::vector<Utterance>& utts, std::vector<UtteranceResult>& out, bool want_latents);
+    // The same in three parts, so a benchmark can time the device-resident middle on its own:
+    //   stage (host -> HBM), run_staged (prefill + frame loop + decode, audio left in HBM), fetch_staged (HBM -> host).
+    // Hold call_mutex() across the three when other threads may use the engine.
+    Batch* stage(const std::vector<Utterance>& utts);
+    void run_staged(Batch& b, std::vector<int>& frames, std::vector<std::vector<float>>* eos_log);
+    void fetch_staged(Batch& b, const std::vector<int>& frames, std::vector<UtteranceResult>& out, bool want_latents);
+    std::recursive_mutex& call_mutex() { return call_mu_; }
+    // Streaming, single utterance: /root/reference/src/pocket_tts.cpp:686-979.  Returns total samples.
+    // cancel_flag (may be null) is polled once per frame when poll_cancel is set, and always suppresses the
+    // tail flush when raised.
+    int generate_streaming(const Utterance& utt, int chunk_frames, const ChunkCallback& cb,
+                           const std::atomic<bool>* cancel_flag, bool poll_cancel, const std::function<void(int)>& progress,
+                           UtteranceResult* capture);
+    // Voice encoder: audio f32[S] at the model rate -> [frames][d_model]  (src/pocket_tts.cpp:261-291)
+    std::vector<float> encode_voice(const float* audio, int S);
+    void encode_voice_batch(const std::vector<const float*>& clips, const std::vector<int>& lens,
+                            std::vector<std::vector<float>>& out);
+
+    // ---- graph-level entry points (one per reference Run call site), host buffers in and out ----
+    void op_text_conditioner(const int64_t* ids, int T, float* out);
+    Batch* batch_new(int B);
+    void batch_free(Batch* b);
+    void batch_reset(Batch* b);
+    void op_lm_prefill(Batch* b, int slot, const float* emb, int rows);
+    void op_lm_step(Batch* b, const float* seq /*[B][latent]*/, float* cond /*[B][d_model]*/, float* eos /*[B]*/);
+    void op_flow_euler(const float* cond, const float* x0, int B, float* x_out);
+    void op_mimi_decode(Batch* b, const float* latents /*[B][n][latent]*/, int n, float* audio /*[B][n*frame]*/);
+
+    // timing hooks for the benchmark: HIP events recorded on the engine stream around named phases
+    struct PhaseTimes { double lm_ms = 0, flow_ms = 0, dec_ms = 0; long lm_calls = 0, flow_calls = 0, dec_calls = 0; };
+    void enable_phase_timing(bool on);
+    PhaseTimes phase_times();
+
+    std::mutex& mutex() { return mu_; }
+
+private:
+    friend class Batch;
+    void transformer(const std::vector<TfLayer>& layers, float* kc, float* vc, long long layer_stride, int cap,
+                     const int* pos_dev, int slot0, int nb, int rpb, float* X, int d, int heads, int ffn, float eps,
+                     int window, const float* cos_tab, const float* sin_tab, int tab_len, const TfScratch& scratch,
+                     float* last_out, long long last_bs, int last_ld);
+    void lm_rows(Batch& b, int slot0, int nb, int rpb, float* X);
+    void lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev);
+    void flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B);
+    void mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs);
+    void prefill_utterance(Batch& b, int slot, const Utterance& u);
+    void fill_noise(std::vector<std::mt19937>& rngs, const std::vector<Utterance>& utts, int step, float* host_x0);
+    Batch* acquire_batch(int B);
+    void phase_begin(int which);
+    void phase_end(int which);
+
+    // Device pointers resolved once at construction (name lookups stay off the per-frame path).
+    struct Handles {
+        std::vector<TfLayer> lm, dec, enc;
+        DevWeight lm_in, flow_cond, flow_in, flow_out, dec_in, dec_conv0, dec_up[3], dec_c1[3], dec_c2[3];
+        DevWeight enc_c1[3], enc_c2[3], enc_down[3], enc_final, enc_ds, enc_spk;
+        const float *bos, *out_g, *out_b, *eos_w, *eos_b, *flow_cond_b, *flow_in_b, *flow_out_b;
+        const float *emb_std, *emb_mean, *dec_up_w, *dec_conv0_b, *dec_up_b[3], *dec_c1_b[3], *dec_c2_b[3], *dec_final_w, *dec_final_b;
+        const float *enc_conv0_w, *enc_conv0_b, *enc_c1_b[3], *enc_c2_b[3], *enc_down_b[3], *enc_final_b, *text_embed;
+    } hd_;
+
+    EngineOptions opt_;
+    std::unique_ptr<Model> model_;
+    hipStream_t stream_ = nullptr;
+    std::mutex mu_;
+    std::recursive_mutex call_mu_;
+    std::mt19937 rng_;
+    DevBuf flow_te_;  // [lsd_steps][C] averaged time embeddings of the fixed (s_j, t_j) grid
+    std::map<int, std::unique_ptr<Batch>> batch_pool_;
+    bool timing_ = false;
+    hipEvent_t ev_[2] = {nullptr, nullptr};
+    PhaseTimes times_;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events_;
+};
+
+// Recurrent state and scratch of B lock-step utterances on one GPU.
+class Batch {
+public:
+    Batch(Engine& e, int B);
+    void reset(hipStream_t s);
+
+    int B;
+    int lm_cap;       // KV capacity per slot (positions)
+    int dec_cap;      // ring capacity of the decoder transformer cache
+    int max_rows;     // scratch rows for transformer passes
+    // LM state
+    DevBuf lm_k, lm_v;      // [layers][B][lm_cap][d_model]
+    DevBuf lm_pos;          // int[B]
+    std::vector<int> lm_pos_host;
+    // decoder state
+    DevBuf dec_k, dec_v;    // [layers][B][dec_cap][mimi_dim]
+    DevBuf dec_pos;         // int[B]
+    long long dec_pos_host = 0;
+    // decoder activation buffers (history rows in front), see engine.cpp for the layout table
+    DevBuf zbuf, qbuf, ybuf, e0buf, ubuf[3], uebuf[3], h1buf[3], ebuf[3];
+    // transformer scratch
+    DevBuf x, h, qkv, q, att, ff;
+    // LM I/O
+    DevBuf seq_in, cond, eos, x0, xcur, latents, ids;
+    TfScratch scratch() const { return TfScratch{h.f(), qkv.f(), q.f(), att.f(), ff.f()}; }
+    // flow scratch
+    DevBuf cemb, ymod, mods;
+    // audio out
+    DevBuf audio;
+    // staged inputs / outputs of a whole batch (Engine::stage / run_staged)
+    DevBuf voice_stage, ids_stage, noise_all, audio_all;
+    std::vector<int> st_voice_frames, st_ntok;
+    int st_vmax = 1;
+    bool st_has_noise = false;
+    // pinned host staging
+    float* h_eos = nullptr;
+    float* h_x0 = nullptr;
+    ~Batch();
+};
+
+}  // namespace ptts

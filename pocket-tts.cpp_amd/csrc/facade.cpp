@@ -1,0 +1,153 @@
+// pocket_tts::PocketTTS on top of the HIP engine: text pre-step, voice clip preparation, path-keyed
+// voice cache and the mapping of the reference's option structs onto engine options.
+// Interface contract: /root/reference/include/pocket_tts/pocket_tts.hpp:78-163; the behaviour of each
+// method follows /root/reference/src/pocket_tts.cpp (encodeVoice :241-297, generate :548-657,
+// generateWithEmbeddings :676-684, generateStreaming :686-979, cancelStreaming :981-983).
+#include <atomic>
+#include <chrono>
+#include <iostream>
+#include <map>
+#include <mutex>
+
+#include "engine.h"
+#include "pocket_tts/audio_utils.hpp"
+#include "pocket_tts/pocket_tts.hpp"
+#include "pocket_tts/tokenizer.hpp"
+
+namespace pocket_tts {
+
+struct PocketTTS::Impl {
+    PocketTTSConfig config;
+    std::unique_ptr<ptts::Engine> engine;
+    std::unique_ptr<Tokenizer> tokenizer;
+    std::mutex cache_mu;
+    std::map<std::string, std::vector<float>> voice_cache;  // keyed by path, like the reference (:75, :243-246)
+    std::atomic<bool> cancel_requested{false};
+
+    explicit Impl(const PocketTTSConfig& cfg) : config(cfg) {
+        ptts::EngineOptions o;
+        o.pack_path = cfg.packPath.empty() ? cfg.modelsDir + "/pocket_tts.ptts" : cfg.packPath;
+        if (cfg.precision == "fp32") o.precision = ptts::Precision::FP32;
+        else if (cfg.precision == "bf16" || cfg.precision == "int8") o.precision = ptts::Precision::BF16;
+        else throw std::runtime_error("unknown precision '" + cfg.precision + "' (expected int8, bf16 or fp32)");
+        o.device = cfg.device;
+        o.lsd_steps = cfg.lsdSteps;
+        o.max_frames = cfg.maxFrames;
+        o.frames_after_eos = cfg.framesAfterEos;
+        o.temperature = cfg.temperature;
+        o.max_text_tokens = cfg.maxTextTokens;
+        o.seed = cfg.seed;
+        o.has_seed = cfg.hasSeed;
+        if (cfg.verbose) std::cout << "Loading weight pack " << o.pack_path << " (precision: " << cfg.precision << ")..." << std::endl;
+        engine = std::make_unique<ptts::Engine>(o);
+        if (cfg.loadTokenizer) {
+            tokenizer = std::make_unique<Tokenizer>(cfg.tokenizerPath);
+            if (cfg.verbose) std::cout << "Tokenizer loaded (vocab size: " << tokenizer->vocabSize() << ")." << std::endl;
+        }
+    }
+
+    std::vector<int64_t> tokenize(const std::string& text) const {
+        if (!tokenizer) throw std::runtime_error("tokenizer not loaded");
+        return tokenizer->encode(text);
+    }
+
+    // 24 kHz mono clip -> conditioning rows.  Only the first 5 s are used (:254-259).
+    std::vector<float> encode_clip(std::vector<float> audio) {
+        if (!config.loadVoiceEncoder) throw std::runtime_error("Voice encoder is disabled (loadVoiceEncoder=false).");
+        const size_t max_samples = static_cast<size_t>(AudioUtils::TARGET_SAMPLE_RATE) * 5;
+        if (audio.size() > max_samples) audio.resize(max_samples);
+        return engine->encode_voice(audio.data(), static_cast<int>(audio.size()));
+    }
+
+    std::vector<float> encode_voice_path(const std::string& path) {
+        {
+            std::lock_guard<std::mutex> lk(cache_mu);
+            auto it = voice_cache.find(path);
+            if (it != voice_cache.end()) return it->second;
+        }
+        auto audio = AudioUtils::loadWav(path, AudioUtils::TARGET_SAMPLE_RATE);  // decode, resample, attenuate (:253)
+        auto emb = encode_clip(std::move(audio));
+        std::lock_guard<std::mutex> lk(cache_mu);
+        voice_cache[path] = emb;
+        return emb;
+    }
+
+    int frames_of(const std::vector<float>& emb, const std::vector<int64_t>& shape) const {
+        const int D = engine->spec().d_model;
+        if (shape.size() >= 2) {
+            int64_t rows = shape[shape.size() - 2];
+            if (rows >= 0 && static_cast<size_t>(rows) * D <= emb.size()) return static_cast<int>(rows);
+        }
+        return static_cast<int>(emb.size() / D);
+    }
+};
+
+PocketTTS::PocketTTS(const PocketTTSConfig& config) : impl_(std::make_unique<Impl>(config)) {}
+PocketTTS::~PocketTTS() = default;
+PocketTTS::PocketTTS(PocketTTS&&) noexcept = default;
+PocketTTS& PocketTTS::operator=(PocketTTS&&) noexcept = default;
+
+ptts::Engine& PocketTTS::engine() { return *impl_->engine; }
+const PocketTTSConfig& PocketTTS::config() const { return impl_->config; }
+std::vector<int64_t> PocketTTS::tokenize(const std::string& text) const { return impl_->tokenize(text); }
+
+std::vector<float> PocketTTS::encodeVoice(const std::string& audioPath) { return impl_->encode_voice_path(audioPath); }
+
+std::vector<float> PocketTTS::encodeVoiceFromSamples(const float* samples, int count, int sampleRate) {
+    std::vector<float> audio(samples, samples + count);
+    if (sampleRate != AudioUtils::TARGET_SAMPLE_RATE) audio = AudioUtils::resample(audio, sampleRate, AudioUtils::TARGET_SAMPLE_RATE);
+    // the reference round-trips through a float32 WAV and loadWav, whose only further effect is the
+    // peak attenuation (src/pocket_tts_c.cpp:96-107 -> src/audio_utils.cpp:156)
+    audio = AudioUtils::normalize(audio);
+    return impl_->encode_clip(std::move(audio));
+}
+
+std::vector<float> PocketTTS::generate(const std::string& text, const std::string& voicePath) {
+    auto t0 = std::chrono::high_resolution_clock::now();
+    auto emb = impl_->encode_voice_path(voicePath);
+    auto audio = generateWithEmbeddings(text, emb, {1, static_cast<int64_t>(emb.size() / impl_->engine->spec().d_model), impl_->engine->spec().d_model});
+    if (impl_->config.verbose) {
+        auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+        float dur = static_cast<float>(audio.size()) / impl_->engine->spec().sample_rate;
+        std::cout << "Generated " << dur << "s audio in " << (ms / 1000.0f) << "s (RTFx: " << dur / (ms / 1000.0f) << "x)" << std::endl;
+    }
+    return audio;
+}
+
+std::vector<float> PocketTTS::generateWithEmbeddings(const std::string& text, const std::vector<float>& voiceEmbeddings,
+                                                     const std::vector<int64_t>& voiceEmbeddingShape) {
+    ptts::Utterance u;
+    u.token_ids = impl_->tokenize(text);
+    u.voice = voiceEmbeddings.data();
+    u.voice_frames = impl_->frames_of(voiceEmbeddings, voiceEmbeddingShape);
+    std::vector<ptts::UtteranceResult> res;
+    impl_->engine->generate({u}, res, false);
+    return std::move(res[0].audio);
+}
+
+int PocketTTS::generateStreaming(const std::string& text, const std::vector<float>& voiceEmbeddings,
+                                 const std::vector<int64_t>& voiceEmbeddingShape, AudioChunkCallback callback,
+                                 const StreamingConfig& streamConfig) {
+    if (!callback) throw std::invalid_argument("Callback must be provided");
+    impl_->cancel_requested = false;  // :698
+    ptts::Utterance u;
+    u.token_ids = impl_->tokenize(text);
+    u.voice = voiceEmbeddings.data();
+    u.voice_frames = impl_->frames_of(voiceEmbeddings, voiceEmbeddingShape);
+    // the tail flush is suppressed by a pending cancel request even when per-frame polling is off (:897)
+    std::function<void(int)> progress;
+    if (streamConfig.onProgress) progress = [&](int frame) { streamConfig.onProgress(frame, 0); };
+    auto t0 = std::chrono::high_resolution_clock::now();
+    int total = impl_->engine->generate_streaming(u, streamConfig.chunkSizeFrames, callback, &impl_->cancel_requested,
+                                                  streamConfig.enableCancellation, progress, nullptr);
+    if (impl_->config.verbose) {
+        auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+        float dur = static_cast<float>(total) / impl_->engine->spec().sample_rate;
+        std::cout << "Streamed " << dur << "s audio in " << (ms / 1000.0f) << "s (RTFx: " << dur / (ms / 1000.0f) << "x)" << std::endl;
+    }
+    return total;
+}
+
+void PocketTTS::cancelStreaming() { impl_->cancel_requested = true; }
+
+}  // namespace pocket_tts

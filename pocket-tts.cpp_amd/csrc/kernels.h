@@ -1,0 +1,117 @@
+// Host-side launch interface of the gfx950 kernels.  All activations are float32, channels-last
+// ([rows][channels]); "batched rows" are addressed as
+//     row m  ->  base + (m / rpb) * batch_stride + (m % rpb) * ld
+// so that one launch covers B utterances whose buffers carry per-utterance history rows in front.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace ptts {
+
+enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_ELU = 3 };
+enum WType : int { W_F32 = 0, W_BF16 = 1 };
+
+// C[m][n] = epilogue( sum_k act_a(A[m][k]) * W[n][k] )
+//   v = acc + bias[n % bias_mod]; v = act_pre(v); v *= G[m][n]; v *= colscale[n] * alpha; v += R[m][n];
+//   rows with (m % rpb) >= row_len[m / rpb] store 0;  C = c_act(v);  C2 = c2_act(v).
+// A rows may overlap (lda < K): that is how a k-tap convolution over channels-last rows is expressed.
+struct GemmArgs {
+    const float* A = nullptr; long long a_bs = 0; int lda = 0;
+    const void* W = nullptr; int wtype = W_F32;
+    float* C = nullptr; long long c_bs = 0; int ldc = 0; int c_act = ACT_NONE;
+    float* C2 = nullptr; long long c2_bs = 0; int ldc2 = 0; int c2_act = ACT_NONE;
+    const float* bias = nullptr; int bias_mod = 0;
+    const float* colscale = nullptr; float alpha = 1.0f;
+    const float* R = nullptr; long long r_bs = 0; int ldr = 0;
+    const float* G = nullptr; long long g_bs = 0; int ldg = 0;
+    const int* row_len = nullptr;
+    int rpb = 1 << 30;
+    int M = 0, N = 0, K = 0;
+    int a_act = ACT_NONE, act_pre = ACT_NONE;
+};
+void launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// Y[m][:] = (X[m][:] - mean) * rstd * g + b   (g, b may be null)
+struct LayerNormArgs {
+    const float* X = nullptr; long long x_bs = 0; int ldx = 0;
+    float* Y = nullptr; long long y_bs = 0; int ldy = 0;
+    int rpb = 1 << 30, M = 0, D = 0;
+    const float* g = nullptr; const float* b = nullptr; float eps = 1e-5f;
+};
+void launch_layernorm(const LayerNormArgs& a, hipStream_t s);
+
+// Split qkv[M][3d], rotate q and k by the row's absolute position (interleaved pairs), write q_out[M][d]
+// and append k, v to the per-slot cache at index pos % cap.  Row m belongs to slot slot0 + m / rpb at
+// position pos[m / rpb] + m % rpb.  cos_tab/sin_tab: [tab_len][dh/2].
+struct RopeAppendArgs {
+    const float* qkv = nullptr; float* q_out = nullptr;
+    float* kcache = nullptr; float* vcache = nullptr;  // [slots][cap][d] of one layer
+    const int* pos = nullptr; int slot0 = 0; int rpb = 1;
+    int M = 0, d = 0, heads = 0, cap = 0;
+    const float* cos_tab = nullptr; const float* sin_tab = nullptr; int tab_len = 0;
+};
+void launch_rope_append(const RopeAppendArgs& a, hipStream_t s);
+
+// out[m][h*64..] = softmax(q . K / 8) V over keys max(0, p-window+1)..p of the row's slot (head dim 64).
+struct AttentionArgs {
+    const float* q = nullptr; float* out = nullptr;
+    const float* kcache = nullptr; const float* vcache = nullptr;
+    const int* pos = nullptr; int slot0 = 0; int rpb = 1;
+    int M = 0, d = 0, heads = 0, cap = 0, window = 0;  // window <= 0: all earlier keys
+};
+void launch_attention(const AttentionArgs& a, hipStream_t s);
+
+// pos[i] += delta for i < n
+void launch_advance_pos(int* pos, int n, int delta, hipStream_t s);
+
+// out[t][:] = table[clamp(ids[t])][:]
+void launch_embed_rows(const long long* ids, int T, const float* table, int vocab_rows, int D, float* out, hipStream_t s);
+
+// mode 0: y = isnan(x) ? bos[c] : x        (BOS substitution in front of the LM input projection)
+// mode 1: y = x * std[c] + mean[c]          (latent de-normalisation in front of the decoder)
+void launch_prep_latent(const float* x, float* y, int rows, int L, int mode, const float* p0, const float* p1, hipStream_t s);
+
+// eos[m] = dot(X[m], w) + b
+void launch_rowdot(const float* X, int ldx, int M, int D, const float* w, const float* b, float* out, hipStream_t s);
+
+// Depthwise transposed conv, kernel 2U stride U: q[B][1 + n][M] (row 0 = previous frame) -> y rows (B*n*U)[M] flat.
+void launch_upsample_dw(const float* q, long long q_bs, int n, int M, int U, const float* w, float* y, int B, hipStream_t s);
+
+// 1-output-channel conv over a contiguous window: out[b][t] = bias + dot(X[b][t .. t+k-1][:], w[k*C])
+void launch_conv_to_mono(const float* X, long long x_bs, int T, int KC, int C, const float* w, const float* bias,
+                         float* out, long long out_bs, int B, hipStream_t s);
+
+// 1-input-channel causal conv: X[b][t][co] = bias[co] + sum_tap w[co][tap] * audio[b][t + tap - (k-1)]
+// writes raw and ELU'd copies; rows t >= len[b] store 0.
+void launch_conv_from_mono(const float* audio, long long a_bs, const int* len, int T, int k, int Co, const float* w,
+                           const float* bias, float* raw, long long raw_bs, float* elu, long long elu_bs, int B,
+                           hipStream_t s);
+
+// Carry history: for each b, rows [T, T+H) of buf[b] move to rows [0, H)  (row length C floats).
+void launch_shift_history(float* buf, long long bs, int T, int H, int C, int B, hipStream_t s);
+
+// ---- fused LSD flow head ------------------------------------------------------------------------
+// One persistent launch runs all `steps` Euler iterations of the flow MLP for every row:
+//   x <- x + dt * v(c, s_j, t_j, x),  j = 0..steps-1
+// mods[j][b][:] holds the precomputed adaLN vectors of Euler step j (they depend on c and j only):
+//   per block (shift, scale, gate) x C, then final (shift, scale) x C.
+struct FlowHeadArgs {
+    const float* x0 = nullptr;    // start points, row b at x0 + b * x0_stride
+    long long x0_stride = 0;
+    float* x_out = nullptr;       // [B][L]
+    const float* mods = nullptr;  // [steps][B][mod_width]
+    int B = 0, L = 0, C = 0, blocks = 0, steps = 0, mod_width = 0;
+    const void* w_in = nullptr; const float* b_in = nullptr;       // [C][L]
+    const void* const* w_fc1 = nullptr; const float* const* b_fc1 = nullptr;  // device arrays of per-block pointers
+    const void* const* w_fc2 = nullptr; const float* const* b_fc2 = nullptr;
+    const float* const* ln_g = nullptr; const float* const* ln_b = nullptr;
+    const void* w_out = nullptr; const float* b_out = nullptr;     // [L][C]
+    int wtype = W_F32;
+    float eps = 1e-6f;
+};
+void launch_flow_head(const FlowHeadArgs& a, hipStream_t s);
+
+// Y[j][b][:] = silu(te[j][:] + cemb[b][:])   (input rows of the stacked adaLN GEMM)
+void launch_flow_mod_input(const float* te, const float* cemb, float* Y, int steps, int B, int C, hipStream_t s);
+
+}  // namespace ptts

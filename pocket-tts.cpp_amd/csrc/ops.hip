@@ -1,0 +1,309 @@
+// Row-wise and state-handling kernels around the GEMMs: LayerNorm, RoPE + KV-cache append, cached
+// attention, embedding gather, latent preparation, the two single-channel convolutions of the codec,
+// the depthwise up-sampler and the history carry of the streaming convolutions.
+// Wave = 64 lanes throughout; the attention head dimension is fixed at 64 so one lane owns one channel.
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+
+#include "kernels.h"
+
+namespace ptts {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------ LayerNorm: one wave per row
+__global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const int b = m / a.rpb, t = m % a.rpb;
+    const float* x = a.X + (long long)b * a.x_bs + (long long)t * a.ldx;
+    float* y = a.Y + (long long)b * a.y_bs + (long long)t * a.ldy;
+    const int D = a.D;
+    float s = 0.f;
+    for (int i = lane * 4; i < D; i += 256) {
+        float4 v = *(const float4*)(x + i);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int i = lane * 4; i < D; i += 256) {
+        float4 v = *(const float4*)(x + i);
+        float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + a.eps);
+    for (int i = lane * 4; i < D; i += 256) {
+        float4 v = *(const float4*)(x + i);
+        float4 o;
+        o.x = (v.x - mean) * rstd; o.y = (v.y - mean) * rstd; o.z = (v.z - mean) * rstd; o.w = (v.w - mean) * rstd;
+        if (a.g) {
+            float4 g = *(const float4*)(a.g + i), bb = *(const float4*)(a.b + i);
+            o.x = o.x * g.x + bb.x; o.y = o.y * g.y + bb.y; o.z = o.z * g.z + bb.z; o.w = o.w * g.w + bb.w;
+        }
+        *(float4*)(y + i) = o;
+    }
+}
+
+void launch_layernorm(const LayerNormArgs& a, hipStream_t s) {
+    if (a.M <= 0) return;
+    if ((a.D & 3) || (a.ldx & 3) || (a.ldy & 3) || (a.x_bs & 3) || (a.y_bs & 3))
+        throw std::runtime_error("layernorm: widths and strides must be multiples of 4");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------ RoPE + KV append
+// One thread per (row, pair): pair index over d/2; q/k pairs rotate, v copies.
+__global__ __launch_bounds__(256) void rope_append_kernel(RopeAppendArgs a) {
+    const int half = a.d >> 1;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.M * half) return;
+    const int m = (int)(idx / half), pi = (int)(idx % half);
+    const int dh2 = (a.d / a.heads) >> 1;
+    const int i = pi % dh2;  // pair index inside the head
+    const int b = m / a.rpb, t = m % a.rpb;
+    const int p = a.pos[b] + t;
+    const int pc = p < a.tab_len ? p : a.tab_len - 1;
+    const float c = a.cos_tab[(long long)pc * dh2 + i], s = a.sin_tab[(long long)pc * dh2 + i];
+    const float* row = a.qkv + (long long)m * 3 * a.d;
+    const float2 q = *(const float2*)(row + 2 * pi);
+    const float2 k = *(const float2*)(row + a.d + 2 * pi);
+    const float2 v = *(const float2*)(row + 2 * a.d + 2 * pi);
+    float2 qo, ko;
+    qo.x = q.x * c - q.y * s; qo.y = q.x * s + q.y * c;
+    ko.x = k.x * c - k.y * s; ko.y = k.x * s + k.y * c;
+    *(float2*)(a.q_out + (long long)m * a.d + 2 * pi) = qo;
+    const long long crow = ((long long)(a.slot0 + b) * a.cap + (p % a.cap)) * a.d + 2 * pi;
+    *(float2*)(a.kcache + crow) = ko;
+    *(float2*)(a.vcache + crow) = v;
+}
+
+void launch_rope_append(const RopeAppendArgs& a, hipStream_t s) {
+    if (a.M <= 0) return;
+    long long n = (long long)a.M * (a.d / 2);
+    hipLaunchKernelGGL(rope_append_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------ cached attention, one wave per (row, head)
+// Pass 1: lane j scores keys j, j+64, ... against q (held by every lane); scores go to LDS.
+// Pass 2: lane e accumulates channel e of the output over all keys (coalesced 256-byte V rows).
+__global__ __launch_bounds__(256) void attention_kernel(AttentionArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long item = (long long)blockIdx.x * 4 + w;
+    const bool live = item < (long long)a.M * a.heads;
+    const int m = live ? (int)(item / a.heads) : 0, h = live ? (int)(item % a.heads) : 0;
+    const int b = m / a.rpb, t = m % a.rpb;
+    const int p = a.pos[b] + t;
+    int j0 = 0;
+    if (a.window > 0 && p - a.window + 1 > 0) j0 = p - a.window + 1;
+    const int nk = live ? (p - j0 + 1) : 0;
+    float* sc = smem + (long long)w * a.cap;
+    const float* kc = a.kcache + (long long)(a.slot0 + b) * a.cap * a.d + h * 64;
+    const float* vc = a.vcache + (long long)(a.slot0 + b) * a.cap * a.d + h * 64;
+    const float* qp = a.q + (long long)m * a.d + h * 64;
+    float4 q[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) q[i] = *(const float4*)(qp + 4 * i);
+    float mx = -INFINITY;
+    for (int j = lane; j < nk; j += 64) {
+        const float* kr = kc + (long long)((j0 + j) % a.cap) * a.d;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float4 kv = *(const float4*)(kr + 4 * i);
+            s0 += q[i].x * kv.x; s1 += q[i].y * kv.y; s2 += q[i].z * kv.z; s3 += q[i].w * kv.w;
+        }
+        float sv = ((s0 + s1) + (s2 + s3)) * 0.125f;
+        sc[j] = sv;
+        mx = fmaxf(mx, sv);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < nk; j += 64) {
+        float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS scores written by other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    int j = 0;
+    for (; j + 4 <= nk; j += 4) {
+        o0 += sc[j] * vc[(long long)((j0 + j) % a.cap) * a.d + lane];
+        o1 += sc[j + 1] * vc[(long long)((j0 + j + 1) % a.cap) * a.d + lane];
+        o2 += sc[j + 2] * vc[(long long)((j0 + j + 2) % a.cap) * a.d + lane];
+        o3 += sc[j + 3] * vc[(long long)((j0 + j + 3) % a.cap) * a.d + lane];
+    }
+    for (; j < nk; ++j) o0 += sc[j] * vc[(long long)((j0 + j) % a.cap) * a.d + lane];
+    if (live) a.out[(long long)m * a.d + h * 64 + lane] = ((o0 + o1) + (o2 + o3)) / sum;
+}
+
+void launch_attention(const AttentionArgs& a, hipStream_t s) {
+    if (a.M <= 0) return;
+    if (a.d != a.heads * 64) throw std::runtime_error("attention: head dimension must be 64");
+    long long items = (long long)a.M * a.heads;
+    size_t smem = (size_t)4 * a.cap * sizeof(float);
+    if (smem > 160 * 1024) throw std::runtime_error("attention: context capacity too large for LDS score buffer");
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), smem, s, a);
+}
+
+// ------------------------------------------------------------------ small helpers
+__global__ void advance_pos_kernel(int* pos, int n, int delta) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pos[i] += delta;
+}
+void launch_advance_pos(int* pos, int n, int delta, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(advance_pos_kernel, dim3((n + 63) / 64), dim3(64), 0, s, pos, n, delta);
+}
+
+__global__ void embed_rows_kernel(const long long* ids, int T, const float* table, int vocab_rows, int D, float* out) {
+    const int t = blockIdx.x;
+    long long id = ids[t];
+    if (id < 0 || id >= vocab_rows) id = vocab_rows - 1;
+    const float4* src = (const float4*)(table + id * D);
+    float4* dst = (float4*)(out + (long long)t * D);
+    for (int i = threadIdx.x; i < D / 4; i += blockDim.x) dst[i] = src[i];
+}
+void launch_embed_rows(const long long* ids, int T, const float* table, int vocab_rows, int D, float* out, hipStream_t s) {
+    if (T <= 0) return;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(T), dim3(256), 0, s, ids, T, table, vocab_rows, D, out);
+}
+
+__global__ void prep_latent_kernel(const float* x, float* y, int n, int L, int mode, const float* p0, const float* p1) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = i % L;
+    float v = x[i];
+    y[i] = mode == 0 ? (isnan(v) ? p0[c] : v) : (v * p0[c] + p1[c]);
+}
+void launch_prep_latent(const float* x, float* y, int rows, int L, int mode, const float* p0, const float* p1, hipStream_t s) {
+    int n = rows * L;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(prep_latent_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n, L, mode, p0, p1);
+}
+
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* X, int ldx, int M, int D, const float* w, const float* b, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* x = X + (long long)m * ldx;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += x[i] * w[i];
+    s = wave_sum(s);
+    if (lane == 0) out[m] = s + b[0];
+}
+void launch_rowdot(const float* X, int ldx, int M, int D, const float* w, const float* b, float* out, hipStream_t s) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((M + 3) / 4), dim3(256), 0, s, X, ldx, M, D, w, b, out);
+}
+
+// y[(b*n + p)*U + r][c] = q[b][1+p][c] * w[c][r] + q[b][p][c] * w[c][r+U]
+__global__ void upsample_dw_kernel(const float* q, long long q_bs, int n, int M, int U, const float* w, float* y, long long total) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int c = (int)(i % M);
+    long long row = i / M;
+    int r = (int)(row % U);
+    long long bp = row / U;
+    int p = (int)(bp % n), b = (int)(bp / n);
+    const float* qb = q + (long long)b * q_bs;
+    y[i] = qb[(long long)(1 + p) * M + c] * w[(long long)c * 2 * U + r] + qb[(long long)p * M + c] * w[(long long)c * 2 * U + r + U];
+}
+void launch_upsample_dw(const float* q, long long q_bs, int n, int M, int U, const float* w, float* y, int B, hipStream_t s) {
+    long long total = (long long)B * n * U * M;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(upsample_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, q, q_bs, n, M, U, w, y, total);
+}
+
+// One wave per 64 consecutive outputs; lane t' computes a dot over its contiguous KC-float window.
+__global__ __launch_bounds__(256) void conv_to_mono_kernel(const float* X, long long x_bs, int T, int KC, int C, const float* w,
+                                                           const float* bias, float* out, long long out_bs) {
+    extern __shared__ float wsh[];
+    for (int i = threadIdx.x; i < KC; i += blockDim.x) wsh[i] = w[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const float* x = X + (long long)b * x_bs + (long long)t * C;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int i = 0; i < KC; i += 4) {
+        float4 v = *(const float4*)(x + i);
+        s0 += v.x * wsh[i]; s1 += v.y * wsh[i + 1]; s2 += v.z * wsh[i + 2]; s3 += v.w * wsh[i + 3];
+    }
+    out[(long long)b * out_bs + t] = ((s0 + s1) + (s2 + s3)) + bias[0];
+}
+void launch_conv_to_mono(const float* X, long long x_bs, int T, int KC, int C, const float* w, const float* bias,
+                         float* out, long long out_bs, int B, hipStream_t s) {
+    if (T <= 0 || B <= 0) return;
+    if ((KC & 3) || (C & 3) || (x_bs & 3)) throw std::runtime_error("conv_to_mono: channel counts must be multiples of 4");
+    hipLaunchKernelGGL(conv_to_mono_kernel, dim3((T + 255) / 256, B), dim3(256), KC * sizeof(float), s, X, x_bs, T, KC, C, w, bias, out, out_bs);
+}
+
+__global__ __launch_bounds__(256) void conv_from_mono_kernel(const float* audio, long long a_bs, const int* len, int T, int k, int Co,
+                                                             const float* w, const float* bias, float* raw, long long raw_bs,
+                                                             float* elu, long long elu_bs) {
+    const int b = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)T * Co) return;
+    const int t = (int)(i / Co), co = (int)(i % Co);
+    const float* au = audio + (long long)b * a_bs;
+    float v = bias[co];
+    for (int tap = 0; tap < k; ++tap) {
+        int src = t + tap - (k - 1);
+        if (src >= 0) v += w[co * k + tap] * au[src];
+    }
+    if (len && t >= len[b]) v = 0.f;
+    if (raw) raw[(long long)b * raw_bs + i] = v;
+    if (elu) elu[(long long)b * elu_bs + i] = v > 0.f ? v : expm1f(v);
+}
+void launch_conv_from_mono(const float* audio, long long a_bs, const int* len, int T, int k, int Co, const float* w,
+                           const float* bias, float* raw, long long raw_bs, float* elu, long long elu_bs, int B, hipStream_t s) {
+    long long n = (long long)T * Co;
+    if (n <= 0 || B <= 0) return;
+    hipLaunchKernelGGL(conv_from_mono_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, s, audio, a_bs, len, T, k, Co, w,
+                       bias, raw, raw_bs, elu, elu_bs);
+}
+
+// One thread per (batch element, channel) walks the H history rows in ascending order, so the copy is
+// a correct forward memmove even when the chunk is shorter than the history (source rows overlap
+// destination rows); threads never share a column.
+__global__ void shift_history_kernel(float* buf, long long bs, int T, int H, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float* base = buf + (long long)blockIdx.y * bs;
+    for (int h = 0; h < H; ++h) base[(long long)h * C + c] = base[(long long)(T + h) * C + c];
+}
+void launch_shift_history(float* buf, long long bs, int T, int H, int C, int B, hipStream_t s) {
+    if (H <= 0 || C <= 0 || B <= 0 || T <= 0) return;
+    hipLaunchKernelGGL(shift_history_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, buf, bs, T, H, C);
+}
+
+__global__ void flow_mod_input_kernel(const float* te, const float* cemb, float* Y, int steps, int B, int C) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)steps * B * C) return;
+    int c = (int)(i % C);
+    long long jb = i / C;
+    int b = (int)(jb % B), j = (int)(jb / B);
+    float v = te[(long long)j * C + c] + cemb[(long long)b * C + c];
+    Y[i] = v / (1.0f + expf(-v));
+}
+void launch_flow_mod_input(const float* te, const float* cemb, float* Y, int steps, int B, int C, hipStream_t s) {
+    long long n = (long long)steps * B * C;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(flow_mod_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, te, cemb, Y, steps, B, C);
+}
+
+}  // namespace ptts

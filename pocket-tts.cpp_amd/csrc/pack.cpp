@@ -1,0 +1,72 @@
+// Weight-pack (.ptts) reader.  The pack replaces the five ONNX files the reference opens in
+// loadModels() (/root/reference/src/pocket_tts.cpp:89-113); layout is documented in pyhost/ptts_pack.py.
+#include "common.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace ptts {
+
+namespace {
+struct RawEntry {
+    char name[64];
+    uint32_t dtype, ndim;
+    uint64_t shape[4], offset, nbytes;
+};
+static_assert(sizeof(RawEntry) == 120, "pack entry layout");
+constexpr size_t kHeaderSize = 16 + 64 * 4 + 16 * 4;
+}  // namespace
+
+Pack::Pack(const std::string& path) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open weight pack: " + path);
+    std::fseek(f, 0, SEEK_END);
+    long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (sz < static_cast<long>(kHeaderSize)) {
+        std::fclose(f);
+        throw std::runtime_error("weight pack too small: " + path);
+    }
+    blob_.resize(static_cast<size_t>(sz));
+    size_t got = std::fread(blob_.data(), 1, blob_.size(), f);
+    std::fclose(f);
+    if (got != blob_.size()) throw std::runtime_error("short read on weight pack: " + path);
+    if (std::memcmp(blob_.data(), "PTTSPK01", 8) != 0) throw std::runtime_error("bad magic in weight pack: " + path);
+    uint32_t ver = 0, n = 0;
+    std::memcpy(&ver, blob_.data() + 8, 4);
+    std::memcpy(&n, blob_.data() + 12, 4);
+    if (ver != 1) throw std::runtime_error("unsupported weight pack version");
+    const int32_t* iv = reinterpret_cast<const int32_t*>(blob_.data() + 16);
+    const float* fv = reinterpret_cast<const float*>(blob_.data() + 16 + 256);
+    Spec& s = spec_;
+    s.latent = iv[0]; s.d_model = iv[1]; s.lm_layers = iv[2]; s.lm_heads = iv[3]; s.lm_ffn = iv[4];
+    s.lm_max_period = iv[5]; s.vocab = iv[6]; s.flow_dim = iv[7]; s.flow_blocks = iv[8]; s.flow_freq = iv[9];
+    s.mimi_dim = iv[10]; s.mimi_layers = iv[11]; s.mimi_heads = iv[12]; s.mimi_ffn = iv[13];
+    s.mimi_context = iv[14]; s.mimi_max_period = iv[15]; s.n_filters = iv[16];
+    s.ratios[0] = iv[17]; s.ratios[1] = iv[18]; s.ratios[2] = iv[19];
+    s.kernel = iv[20]; s.last_kernel = iv[21]; s.res_kernel = iv[22]; s.upsample = iv[23]; s.sample_rate = iv[24];
+    s.lm_eps = fv[0]; s.flow_eps = fv[1]; s.mimi_eps = fv[2]; s.flow_max_period = fv[3];
+    if (kHeaderSize + static_cast<size_t>(n) * sizeof(RawEntry) > blob_.size())
+        throw std::runtime_error("weight pack tensor table truncated");
+    for (uint32_t i = 0; i < n; ++i) {
+        RawEntry e;
+        std::memcpy(&e, blob_.data() + kHeaderSize + i * sizeof(RawEntry), sizeof(RawEntry));
+        if (e.dtype != 0) throw std::runtime_error("weight pack: only f32 tensors are supported");
+        if (e.offset + e.nbytes > blob_.size() || e.ndim > 4) throw std::runtime_error("weight pack: bad tensor entry");
+        HostTensor t;
+        t.data = reinterpret_cast<const float*>(blob_.data() + e.offset);
+        for (uint32_t d = 0; d < e.ndim; ++d) t.shape.push_back(static_cast<int64_t>(e.shape[d]));
+        char nm[65];
+        std::memcpy(nm, e.name, 64);
+        nm[64] = 0;
+        tensors_[nm] = t;
+    }
+}
+
+const HostTensor& Pack::get(const std::string& name) const {
+    auto it = tensors_.find(name);
+    if (it == tensors_.end()) throw std::runtime_error("weight pack: missing tensor " + name);
+    return it->second;
+}
+
+}  // namespace ptts

@@ -1,0 +1,118 @@
+"""GPU parity, one test per reference graph call site: the HIP path (through the C ABI) against the
+C oracle on the same seeded inputs.  Tolerances: f32 path max-abs 1e-3 on latents/conditioning (the
+bound the project states for fp32), bf16 path 2e-2; decoded audio SNR >= 40 dB for f32."""
+import numpy as np
+import pytest
+
+from conftest import snr_db
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-3
+BF16_TOL = 2e-2
+
+
+@pytest.fixture(scope="module")
+def ptts():
+    import ptts_lib
+    ptts_lib.load()
+    return ptts_lib
+
+
+def _engine(ptts, packs, name, precision="fp32", **kw):
+    path, spec, _ = packs[name]
+    return ptts.Engine(path, precision=precision, **kw), spec
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_text_conditioner_bit_exact(ptts, packs, oracle_mod, name):
+    eng, spec = _engine(ptts, packs, name)
+    o = oracle_mod.Oracle(packs[name][0])
+    ids = np.array([0, 1, spec.vocab - 1, spec.vocab, 5, 5, 17], np.int64)
+    np.testing.assert_array_equal(eng.text_conditioner(ids), o.text_conditioner(ids))
+    eng.close()
+
+
+@pytest.mark.parametrize("name,precision,tol", [("tiny", "fp32", F32_TOL), ("small", "fp32", F32_TOL), ("small", "bf16", BF16_TOL * 5)])
+def test_lm_prefill_and_steps(ptts, packs, oracle_mod, name, precision, tol):
+    eng, spec = _engine(ptts, packs, name, precision)
+    o = oracle_mod.Oracle(packs[name][0])
+    rng = np.random.default_rng(3)
+    B, S = 3, 5
+    voices = [(rng.standard_normal((nv, spec.d_model)) * 0.5).astype(np.float32) for nv in (4, 9, 1)]
+    texts = [o.text_conditioner(rng.integers(0, spec.vocab, t)) for t in (7, 3, 12)]
+    seq = rng.standard_normal((S, B, spec.latent_dim)).astype(np.float32)
+    seq[0] = np.nan
+    st = eng.state(B)
+    for b in range(B):
+        eng.lm_prefill(st, b, voices[b])
+        eng.lm_prefill(st, b, texts[b])
+    ost = [o.lm_state(128) for _ in range(B)]
+    for b in range(B):
+        o.lm_main(ost[b], None, voices[b])
+        o.lm_main(ost[b], None, texts[b])
+    worst = 0.0
+    for s in range(S):
+        cond, eos = eng.lm_step(st, seq[s])
+        for b in range(B):
+            oc, oe = o.lm_main(ost[b], seq[s, b:b + 1], None)
+            worst = max(worst, np.abs(cond[b] - oc).max(), abs(eos[b] - oe))
+    assert worst < tol, worst
+    st.close(); eng.close()
+
+
+@pytest.mark.parametrize("name,precision,tol,rows", [("tiny", "fp32", F32_TOL, 5), ("small", "fp32", F32_TOL, 37), ("small", "bf16", BF16_TOL * 5, 16)])
+def test_flow_euler(ptts, packs, oracle_mod, name, precision, tol, rows):
+    eng, spec = _engine(ptts, packs, name, precision, lsd_steps=10)
+    o = oracle_mod.Oracle(packs[name][0])
+    rng = np.random.default_rng(5)
+    cond = rng.standard_normal((rows, spec.d_model)).astype(np.float32)
+    x0 = (rng.standard_normal((rows, spec.latent_dim)) * 0.8).astype(np.float32)
+    x0[0] = 0.0
+    got = eng.flow_euler(cond, x0)
+    want = np.stack([o.flow_euler(cond[i], x0[i], 10) for i in range(rows)])
+    assert np.abs(got - want).max() < tol, np.abs(got - want).max()
+    eng.close()
+
+
+@pytest.mark.parametrize("name,precision", [("tiny", "fp32"), ("small", "fp32"), ("small", "bf16")])
+def test_mimi_decode_streaming_chunks(ptts, packs, oracle_mod, name, precision):
+    eng, spec = _engine(ptts, packs, name, precision)
+    o = oracle_mod.Oracle(packs[name][0])
+    rng = np.random.default_rng(9)
+    B = 2
+    sizes = [3, 1, 15, 4, 2] if name == "tiny" else [3, 1, 5]
+    F = sum(sizes)
+    lat = rng.standard_normal((B, F, spec.latent_dim)).astype(np.float32)
+    st = eng.state(B)
+    got = [[] for _ in range(B)]
+    f0 = 0
+    for n in sizes:
+        a = eng.mimi_decode(st, lat[:, f0:f0 + n])
+        for b in range(B):
+            got[b].append(a[b])
+        f0 += n
+    for b in range(B):
+        ds = o.dec_state()
+        want = np.concatenate([o.mimi_decode(ds, lat[b, i:i + 1]) for i in range(F)])  # frame-by-frame: chunking must not matter
+        g = np.concatenate(got[b])
+        snr = snr_db(want, g)
+        if precision == "fp32":
+            assert snr >= 60.0, snr
+            assert np.abs(g - want).max() < 1e-3 * max(1.0, np.abs(want).max())
+        else:
+            assert snr >= 20.0, snr
+    st.close(); eng.close()
+
+
+@pytest.mark.parametrize("name,samples", [("tiny", 500), ("tiny", 48), ("tiny", 1), ("small", 4000)])
+def test_mimi_encode(ptts, packs, oracle_mod, name, samples):
+    eng, spec = _engine(ptts, packs, name)
+    o = oracle_mod.Oracle(packs[name][0])
+    rng = np.random.default_rng(13)
+    audio = (rng.standard_normal(samples) * 0.3).astype(np.float32)
+    got = eng.mimi_encode(audio)
+    want = o.mimi_encode(audio)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < F32_TOL, np.abs(got - want).max()
+    eng.close()
