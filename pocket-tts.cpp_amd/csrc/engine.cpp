@@ -148,13 +148,23 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     ada_all.K = C;
     ada_all_b = reinterpret_cast<const float*>(static_cast<unsigned char*>(blob_f32_.p) + ada_b_off);
 
-    // per-block pointer tables for the fused flow head
+    // fused flow head: fragment-major copies of its sequential weights + per-block pointer tables
     const int nb = s.flow_blocks;
+    flow_wtype = prec_ == Precision::BF16 ? W_BF16 : W_F32;
+    auto packed = [&](const std::string& name) -> const void* {
+        const HostTensor& t = pack.get(name);
+        auto bytes = pack_flow_weight(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), flow_wtype);
+        extra_.emplace_back(bytes.size());
+        PTTS_HIP(hipMemcpy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+        return extra_.back().p;
+    };
+    flow_in_packed = packed("flow.in_proj.w");
+    flow_out_packed = packed("flow.final.lin.w");
     std::vector<const void*> tab(static_cast<size_t>(6) * nb);
     for (int i = 0; i < nb; ++i) {
         std::string p = "flow.b" + std::to_string(i) + ".";
-        tab[0 * nb + i] = w(p + "fc1.w").p;
-        tab[1 * nb + i] = w(p + "fc2.w").p;
+        tab[0 * nb + i] = packed(p + "fc1.w");
+        tab[1 * nb + i] = packed(p + "fc2.w");
         tab[2 * nb + i] = f(p + "fc1.b");
         tab[3 * nb + i] = f(p + "fc2.b");
         tab[4 * nb + i] = f(p + "ln.g");
@@ -280,7 +290,10 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     size_t xe = std::max(rows_lm * D, rows_dec * M);
     x.alloc(xe * 4); h.alloc(xe * 4); q.alloc(xe * 4); att.alloc(xe * 4);
     qkv.alloc(xe * 3 * 4);
-    ff.alloc(std::max(rows_lm * s.lm_ffn, rows_dec * s.mimi_ffn) * 4);
+    scratch_rows_d = xe;
+    scratch_rows_f = std::max(rows_lm * s.lm_ffn, rows_dec * s.mimi_ffn);
+    ff.alloc(scratch_rows_f * 4);
+    st_nv.alloc(static_cast<size_t>(B) * 4); st_nt.alloc(static_cast<size_t>(B) * 4); st_len.alloc(static_cast<size_t>(B) * 4);
     (void)dmax; (void)fmax;
     seq_in.alloc(static_cast<size_t>(B) * L * 4);
     cond.alloc(static_cast<size_t>(B) * D * 4);
@@ -314,6 +327,21 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_eos), static_cast<size_t>(B) * 4));
     PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_x0), static_cast<size_t>(B) * L * 4));
     reset(e.stream());
+}
+
+// Grow the transformer scratch so that a pass over `rows` rows of width d (FFN width ffn) fits.
+void Batch::ensure_rows(size_t rows, int d, int ffn) {
+    const size_t need_d = rows * d, need_f = rows * ffn;
+    if (need_d > scratch_rows_d) {
+        PTTS_HIP(hipDeviceSynchronize());
+        x.alloc(need_d * 4); h.alloc(need_d * 4); q.alloc(need_d * 4); att.alloc(need_d * 4); qkv.alloc(need_d * 3 * 4);
+        scratch_rows_d = need_d;
+    }
+    if (need_f > scratch_rows_f) {
+        PTTS_HIP(hipDeviceSynchronize());
+        ff.alloc(need_f * 4);
+        scratch_rows_f = need_f;
+    }
 }
 
 Batch::~Batch() {
@@ -521,17 +549,20 @@ void Engine::transformer(const std::vector<TfLayer>& layers, float* kc, float* v
     }
 }
 
-void Engine::lm_rows(Batch& b, int slot0, int nb, int rpb, float* X) {
+// adv_dev / adv_host (optional): per-slot position advance when the nb x rpb rows are padded to a common length.
+void Engine::lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* adv_dev, const int* adv_host) {
     const Spec& s = spec();
     for (int i = 0; i < nb; ++i)
         if (b.lm_pos_host[slot0 + i] + rpb > b.lm_cap)
             throw std::runtime_error("LM context exceeds the KV-cache capacity (voice + text + frames too long)");
+    b.ensure_rows(static_cast<size_t>(nb) * rpb, s.d_model, s.lm_ffn);
     const auto& layers = hd_.lm;
     const long long layer_stride = static_cast<long long>(b.B) * b.lm_cap * s.d_model;
     transformer(layers, b.lm_k.f(), b.lm_v.f(), layer_stride, b.lm_cap, b.lm_pos.as<int>() + slot0, slot0, nb, rpb, X, s.d_model,
                 s.lm_heads, s.lm_ffn, s.lm_eps, 0, model_->lm_cos, model_->lm_sin, model_->lm_tab_len, b.scratch(), nullptr, 0, 0);
-    launch_advance_pos(b.lm_pos.as<int>() + slot0, nb, rpb, stream_);
-    for (int i = 0; i < nb; ++i) b.lm_pos_host[slot0 + i] += rpb;
+    if (adv_dev) launch_advance_pos_vec(b.lm_pos.as<int>() + slot0, adv_dev, nb, stream_);
+    else launch_advance_pos(b.lm_pos.as<int>() + slot0, nb, rpb, stream_);
+    for (int i = 0; i < nb; ++i) b.lm_pos_host[slot0 + i] += adv_host ? adv_host[i] : rpb;
 }
 
 // sequence[B][latent] (NaN = BOS) -> conditioning[B][d_model], eos[B]   (src/pocket_tts.cpp:323-411, decode shape)
@@ -571,10 +602,9 @@ void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long
     FlowHeadArgs fa;
     fa.x0 = x0_dev; fa.x0_stride = x0_stride; fa.x_out = x_out_dev; fa.mods = b.mods.f(); fa.B = B; fa.L = s.latent; fa.C = C; fa.blocks = s.flow_blocks;
     fa.steps = N; fa.mod_width = model_->mod_width;
-    const DevWeight &win = hd_.flow_in, &wout = hd_.flow_out;
-    fa.w_in = win.p; fa.b_in = hd_.flow_in_b; fa.w_out = wout.p; fa.b_out = hd_.flow_out_b;
+    fa.w_in = model_->flow_in_packed; fa.b_in = hd_.flow_in_b; fa.w_out = model_->flow_out_packed; fa.b_out = hd_.flow_out_b;
     fa.w_fc1 = model_->d_w_fc1; fa.w_fc2 = model_->d_w_fc2; fa.b_fc1 = model_->d_b_fc1; fa.b_fc2 = model_->d_b_fc2;
-    fa.ln_g = model_->d_ln_g; fa.ln_b = model_->d_ln_b; fa.wtype = win.wtype; fa.eps = s.flow_eps;
+    fa.ln_g = model_->d_ln_g; fa.ln_b = model_->d_ln_b; fa.wtype = model_->flow_wtype; fa.eps = s.flow_eps;
     launch_flow_head(fa, stream_);
     phase_end(1);
 }

@@ -51,6 +51,8 @@ public:
     const void* const* d_w_fc1 = nullptr; const void* const* d_w_fc2 = nullptr;
     const float* const* d_b_fc1 = nullptr; const float* const* d_b_fc2 = nullptr;
     const float* const* d_ln_g = nullptr; const float* const* d_ln_b = nullptr;
+    const void *flow_in_packed = nullptr, *flow_out_packed = nullptr;  // fragment-major flow.in_proj.w / flow.final.lin.w
+    int flow_wtype = W_F32;
 
     void build_rope_tables(int lm_len, int mimi_len);
 
@@ -151,7 +153,7 @@ private:
                      const int* pos_dev, int slot0, int nb, int rpb, float* X, int d, int heads, int ffn, float eps,
                      int window, const float* cos_tab, const float* sin_tab, int tab_len, const TfScratch& scratch,
                      float* last_out, long long last_bs, int last_ld);
-    void lm_rows(Batch& b, int slot0, int nb, int rpb, float* X);
+    void lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* adv_dev = nullptr, const int* adv_host = nullptr);
     void lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev);
     void flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B);
     void mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs);
@@ -205,8 +207,11 @@ public:
     long long dec_pos_host = 0;
     // decoder activation buffers (history rows in front), see engine.cpp for the layout table
     DevBuf zbuf, qbuf, ybuf, e0buf, ubuf[3], uebuf[3], h1buf[3], ebuf[3];
-    // transformer scratch
+    // transformer scratch (grown on demand by ensure_rows)
     DevBuf x, h, qkv, q, att, ff;
+    size_t scratch_rows_d = 0, scratch_rows_f = 0;  // capacity in floats of x/h/q/att and of ff
+    void ensure_rows(size_t rows, int d, int ffn);
+    DevBuf st_nv, st_nt, st_len;  // per-slot int arrays of the staged batch
     // LM I/O
     DevBuf seq_in, cond, eos, x0, xcur, latents, ids;
     TfScratch scratch() const { return TfScratch{h.f(), qkv.f(), q.f(), att.f(), ff.f()}; }

@@ -131,21 +131,22 @@ void Engine::run_staged(Batch& b, std::vector<int>& frames, std::vector<std::vec
     const Spec& s = spec();
     const int B = b.B, L = s.latent, D = s.d_model, fs = s.frame_size();
     b.reset(stream_);
-    // voice rows, then text rows, per utterance (two passes like the reference's two prefill Runs, :572, :575)
-    const int chunk = 256;
-    for (int i = 0; i < B; ++i) {
-        for (int r0 = 0; r0 < b.st_voice_frames[i]; r0 += chunk) {
-            const int n = std::min(chunk, b.st_voice_frames[i] - r0);
-            PTTS_HIP(hipMemcpyAsync(b.x.p, b.voice_stage.f() + (static_cast<size_t>(i) * b.st_vmax + r0) * D, static_cast<size_t>(n) * D * 4,
-                                    hipMemcpyDeviceToDevice, stream_));
-            lm_rows(b, i, 1, n, b.x.f());
-        }
-        for (int r0 = 0; r0 < b.st_ntok[i]; r0 += chunk) {
-            const int n = std::min(chunk, b.st_ntok[i] - r0);
-            launch_embed_rows(b.ids_stage.as<long long>() + static_cast<size_t>(i) * opt_.max_text_tokens + r0, n, hd_.text_embed, s.vocab + 1, D,
-                              b.x.f(), stream_);
-            lm_rows(b, i, 1, n, b.x.f());
-        }
+    // Prefill.  The reference feeds the voice rows and then the text rows of an utterance as two causal passes
+    // (:572, :575); one causal pass over [voice; text] writes the same KV cache.  All utterances go through
+    // together, padded to the longest; padding rows land beyond each utterance's real length in its cache,
+    // are never attended to by real rows, and are overwritten by the frames that follow.
+    {
+        int rpb = 1;
+        std::vector<int> len(B);
+        for (int i = 0; i < B; ++i) { len[i] = b.st_voice_frames[i] + b.st_ntok[i]; rpb = std::max(rpb, len[i]); }
+        PTTS_HIP(hipMemcpyAsync(b.st_nv.p, b.st_voice_frames.data(), static_cast<size_t>(B) * 4, hipMemcpyHostToDevice, stream_));
+        PTTS_HIP(hipMemcpyAsync(b.st_nt.p, b.st_ntok.data(), static_cast<size_t>(B) * 4, hipMemcpyHostToDevice, stream_));
+        PTTS_HIP(hipMemcpyAsync(b.st_len.p, len.data(), static_cast<size_t>(B) * 4, hipMemcpyHostToDevice, stream_));
+        PTTS_HIP(hipStreamSynchronize(stream_));  // len[] is a local
+        b.ensure_rows(static_cast<size_t>(B) * rpb, D, s.lm_ffn);
+        launch_assemble_prefill(b.voice_stage.f(), static_cast<long long>(b.st_vmax) * D, b.ids_stage.as<long long>(), opt_.max_text_tokens,
+                                b.st_nv.as<int>(), b.st_nt.as<int>(), hd_.text_embed, s.vocab + 1, D, rpb, B, b.x.f(), stream_);
+        lm_rows(b, 0, B, rpb, b.x.f(), b.st_len.as<int>(), len.data());
     }
     // BOS marker: NaN latent (:579)
     for (int i = 0; i < B * L; ++i) b.h_x0[i] = std::numeric_limits<float>::quiet_NaN();

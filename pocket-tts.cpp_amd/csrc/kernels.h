@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 namespace ptts {
 
 enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_ELU = 3 };
@@ -63,6 +65,13 @@ void launch_attention(const AttentionArgs& a, hipStream_t s);
 
 // pos[i] += delta for i < n
 void launch_advance_pos(int* pos, int n, int delta, hipStream_t s);
+// pos[i] += delta[i] for i < n
+void launch_advance_pos_vec(int* pos, const int* delta, int n, hipStream_t s);
+
+// Prefill rows of a whole batch: out[b][t][:] = voice[b][t][:] for t < nv[b], the embedding of
+// ids[b][t - nv[b]] for the next nt[b] rows, zero for the padding up to rpb rows.
+void launch_assemble_prefill(const float* voice, long long voice_bs, const long long* ids, int ids_stride, const int* nv, const int* nt,
+                             const float* table, int vocab_rows, int D, int rpb, int B, float* out, hipStream_t s);
 
 // out[t][:] = table[clamp(ids[t])][:]
 void launch_embed_rows(const long long* ids, int T, const float* table, int vocab_rows, int D, float* out, hipStream_t s);
@@ -101,6 +110,7 @@ struct FlowHeadArgs {
     float* x_out = nullptr;       // [B][L]
     const float* mods = nullptr;  // [steps][B][mod_width]
     int B = 0, L = 0, C = 0, blocks = 0, steps = 0, mod_width = 0;
+    // all weights below are in pack_flow_weight layout
     const void* w_in = nullptr; const float* b_in = nullptr;       // [C][L]
     const void* const* w_fc1 = nullptr; const float* const* b_fc1 = nullptr;  // device arrays of per-block pointers
     const void* const* w_fc2 = nullptr; const float* const* b_fc2 = nullptr;
@@ -110,6 +120,8 @@ struct FlowHeadArgs {
     float eps = 1e-6f;
 };
 void launch_flow_head(const FlowHeadArgs& a, hipStream_t s);
+// Host-side reorder of a flow-head weight W[N][K] into the fragment-major layout the kernel streams.
+std::vector<unsigned char> pack_flow_weight(const float* W, int N, int K, int wtype);
 
 // Y[j][b][:] = silu(te[j][:] + cemb[b][:])   (input rows of the stacked adaLN GEMM)
 void launch_flow_mod_input(const float* te, const float* cemb, float* Y, int steps, int B, int C, hipStream_t s);

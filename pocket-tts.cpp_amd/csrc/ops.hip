@@ -169,6 +169,37 @@ void launch_advance_pos(int* pos, int n, int delta, hipStream_t s) {
     hipLaunchKernelGGL(advance_pos_kernel, dim3((n + 63) / 64), dim3(64), 0, s, pos, n, delta);
 }
 
+__global__ void advance_pos_vec_kernel(int* pos, const int* delta, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pos[i] += delta[i];
+}
+void launch_advance_pos_vec(int* pos, const int* delta, int n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(advance_pos_vec_kernel, dim3((n + 63) / 64), dim3(64), 0, s, pos, delta, n);
+}
+
+__global__ void assemble_prefill_kernel(const float* voice, long long voice_bs, const long long* ids, int ids_stride, const int* nv,
+                                        const int* nt, const float* table, int vocab_rows, int D, int rpb, float* out) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int v = nv[b], n = nt[b];
+    float4* dst = (float4*)(out + ((long long)b * rpb + t) * D);
+    const float4* src = nullptr;
+    if (t < v) {
+        src = (const float4*)(voice + (long long)b * voice_bs + (long long)t * D);
+    } else if (t < v + n) {
+        long long id = ids[(long long)b * ids_stride + (t - v)];
+        if (id < 0 || id >= vocab_rows) id = vocab_rows - 1;
+        src = (const float4*)(table + id * D);
+    }
+    for (int i = threadIdx.x; i < D / 4; i += blockDim.x) dst[i] = src ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+void launch_assemble_prefill(const float* voice, long long voice_bs, const long long* ids, int ids_stride, const int* nv, const int* nt,
+                             const float* table, int vocab_rows, int D, int rpb, int B, float* out, hipStream_t s) {
+    if (rpb <= 0 || B <= 0) return;
+    hipLaunchKernelGGL(assemble_prefill_kernel, dim3(rpb, B), dim3(256), 0, s, voice, voice_bs, ids, ids_stride, nv, nt, table, vocab_rows,
+                       D, rpb, out);
+}
+
 __global__ void embed_rows_kernel(const long long* ids, int T, const float* table, int vocab_rows, int D, float* out) {
     const int t = blockIdx.x;
     long long id = ids[t];
