@@ -110,6 +110,21 @@ POCKET_TTS_API int ptts_mimi_decode(PocketTTSHandle handle, void* state, const f
  * or -1                                                             (src/pocket_tts.cpp:261-291). */
 POCKET_TTS_API int ptts_mimi_encode(PocketTTSHandle handle, const float* audio, int samples, float* out, int cap_frames);
 
+/* ---- host-side pre/post steps, usable without a GPU ---------------------------------------------- */
+
+/* Text pre-step on its own (src/tokenizer.cpp:14-60).  raw != 0 skips the sentence clean-up. */
+POCKET_TTS_API void* ptts_tokenizer_new(const char* model_path);
+POCKET_TTS_API void ptts_tokenizer_free(void* tokenizer);
+POCKET_TTS_API int ptts_tokenizer_vocab(void* tokenizer);
+POCKET_TTS_API int ptts_tokenizer_encode(void* tokenizer, const char* text, int raw, long long* ids, int cap);
+
+/* AudioUtils of the reference (src/audio_utils.cpp:45-303).  Each returns the output length (writing at
+ * most cap samples) or -1. */
+POCKET_TTS_API int ptts_audio_load_wav(const char* path, int target_rate, float* out, int cap);
+POCKET_TTS_API int ptts_audio_save_wav(const char* path, const float* samples, int n, int rate);
+POCKET_TTS_API int ptts_audio_resample(const float* in, int n, int in_rate, int out_rate, float* out, int cap);
+POCKET_TTS_API int ptts_audio_normalize(const float* in, int n, float* out);
+
 /* Benchmark support: HIP-event timing of the three per-frame phases on the engine's stream.
  * times_ms[0..2] = LM step, flow head, decoder chunk totals; calls[0..2] = launches of each. */
 POCKET_TTS_API int ptts_phase_timing(PocketTTSHandle handle, int enable);

@@ -9,6 +9,7 @@
 #include "pocket_tts/audio_utils.hpp"
 #include "pocket_tts/pocket_tts.hpp"
 #include "pocket_tts/pocket_tts_amd.h"
+#include "pocket_tts/tokenizer.hpp"
 
 namespace {
 
@@ -410,6 +411,63 @@ POCKET_TTS_API int ptts_mimi_encode(PocketTTSHandle handle, const float* audio, 
         std::memcpy(out, emb.data(), static_cast<size_t>(std::min(frames, cap_frames)) * D * 4);
         return frames;
     });
+}
+
+POCKET_TTS_API void* ptts_tokenizer_new(const char* model_path) {
+    if (!model_path) { set_error("Invalid parameters"); return nullptr; }
+    try {
+        return new pocket_tts::Tokenizer(model_path);
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return nullptr;
+    }
+}
+
+POCKET_TTS_API void ptts_tokenizer_free(void* tokenizer) { delete static_cast<pocket_tts::Tokenizer*>(tokenizer); }
+
+POCKET_TTS_API int ptts_tokenizer_vocab(void* tokenizer) {
+    return tokenizer ? static_cast<pocket_tts::Tokenizer*>(tokenizer)->vocabSize() : -1;
+}
+
+POCKET_TTS_API int ptts_tokenizer_encode(void* tokenizer, const char* text, int raw, long long* ids, int cap) {
+    if (!tokenizer || !text) { set_error("Invalid parameters"); return -1; }
+    return guarded("tokenize: ", [&] {
+        auto* t = static_cast<pocket_tts::Tokenizer*>(tokenizer);
+        auto v = raw ? t->encodeRaw(text) : t->encode(text);
+        for (int i = 0; i < cap && i < static_cast<int>(v.size()); ++i) ids[i] = v[i];
+        return static_cast<int>(v.size());
+    });
+}
+
+static int copy_out(const std::vector<float>& v, float* out, int cap) {
+    const int n = static_cast<int>(v.size());
+    if (out && cap > 0) std::memcpy(out, v.data(), sizeof(float) * static_cast<size_t>(std::min(n, cap)));
+    return n;
+}
+
+POCKET_TTS_API int ptts_audio_load_wav(const char* path, int target_rate, float* out, int cap) {
+    if (!path) { set_error("Invalid parameters"); return -1; }
+    return guarded("", [&] { return copy_out(pocket_tts::AudioUtils::loadWav(path, target_rate), out, cap); });
+}
+
+POCKET_TTS_API int ptts_audio_save_wav(const char* path, const float* samples, int n, int rate) {
+    if (!path || (!samples && n > 0) || n < 0) { set_error("Invalid parameters"); return -1; }
+    return guarded("", [&] {
+        pocket_tts::AudioUtils::saveWav(path, std::vector<float>(samples, samples + n), rate);
+        return 0;
+    });
+}
+
+POCKET_TTS_API int ptts_audio_resample(const float* in, int n, int in_rate, int out_rate, float* out, int cap) {
+    if ((!in && n > 0) || n < 0) { set_error("Invalid parameters"); return -1; }
+    return guarded("", [&] {
+        return copy_out(pocket_tts::AudioUtils::resample(std::vector<float>(in, in + n), in_rate, out_rate), out, cap);
+    });
+}
+
+POCKET_TTS_API int ptts_audio_normalize(const float* in, int n, float* out) {
+    if ((!in && n > 0) || n < 0) { set_error("Invalid parameters"); return -1; }
+    return guarded("", [&] { return copy_out(pocket_tts::AudioUtils::normalize(std::vector<float>(in, in + n)), out, n); });
 }
 
 POCKET_TTS_API int ptts_phase_timing(PocketTTSHandle handle, int enable) {

@@ -1,0 +1,346 @@
+// Kernels of the batched autoregressive LM step (one new token per utterance, M = batch rows <= a few
+// hundred).  At this shape every matrix product is a weight-streaming problem, so the three kernels are
+// built around that:
+//
+//  skinny_gemm   M x N x K with M tiled by 64: a workgroup of 4 waves owns 64 output columns and a K-slice;
+//                wave w owns column tile w for all row tiles.  Weights are fragment-major (one wave-level
+//                load = 1 KiB contiguous = one MFMA B operand per lane) and go L2 -> VGPR one K-chunk ahead
+//                of use; activations (already in the compute type) go through a double-buffered LDS tile
+//                shared by the 4 waves.  Long K is split over workgroups into f32 partial slabs.
+//  add_norm      the consumer of those slabs: per row, sums the K-slices in a fixed order (bitwise
+//                reproducible), applies layer scale and the residual, then LayerNorms the updated row for
+//                the next matrix product (and, for the last layer, emits conditioning + EOS logit).
+//  attn_decode   RoPE, KV-cache append and single-query attention for one (row, head) per wave.
+//
+// f32 weights use v_mfma_f32_16x16x4_f32 (exact f32 FMA chain), bf16 weights v_mfma_f32_16x16x32_bf16.
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace ptts {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <typename CT> struct SkinnyTraits { static constexpr int kstep = 16, per = 4, kch = 128, pad = 4; };
+template <> struct SkinnyTraits<__bf16> { static constexpr int kstep = 32, per = 8, kch = 256, pad = 8; };
+
+__device__ __forceinline__ float act_dev(float v, int act) {
+    switch (act) {
+        case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case ACT_SILU: return v / (1.0f + expf(-v));
+        case ACT_ELU: return v > 0.f ? v : expm1f(v);
+        default: return v;
+    }
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
+    using T = SkinnyTraits<CT>;
+    constexpr int KSTEP = T::kstep, PER = T::per, KCH = T::kch, LDA = KCH + T::pad;
+    constexpr int NKS = KCH / KSTEP;                   // k-steps per chunk (8)
+    constexpr int PIECES = KCH * (int)sizeof(CT) / 16;  // 16-byte pieces per row of a chunk (32)
+    constexpr int APT = 64 * PIECES / 256;              // A pieces per thread per chunk (8)
+    __shared__ __attribute__((aligned(16))) CT As[2][64 * LDA];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x * 4 + wave;
+    const bool tile_live = nt * 16 < a.N;
+    const int m0 = blockIdx.z * 64;
+    const int Kc = a.K / a.splits;
+    const int k_begin = blockIdx.y * Kc;
+    const int nchunks = (Kc + KCH - 1) / KCH;
+    const int KS_total = a.K / KSTEP;
+    const uint4* wbase = (const uint4*)a.Wp + (long long)nt * KS_total * 64 + lane;
+
+    uint4 areg[APT], bnext[NKS], bcur[NKS];
+    auto load_chunk = [&](int c) {
+        const int kc0 = c * KCH;  // offset inside the slice
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int id = tid + 256 * i, row = id / PIECES, piece = id % PIECES;
+            const int k = kc0 + piece * (16 / (int)sizeof(CT));
+            const bool ok = (m0 + row) < a.M && k < Kc;
+            areg[i] = ok ? *(const uint4*)((const CT*)a.A + (long long)(m0 + row) * a.lda + k_begin + k) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < NKS; ++i) {
+            const int k = kc0 + i * KSTEP;
+            bnext[i] = (tile_live && k < Kc) ? wbase[(long long)((k_begin + k) / KSTEP) * 64] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, g = lane >> 4;
+
+    load_chunk(0);
+    for (int c = 0; c < nchunks; ++c) {
+        CT* buf = As[c & 1];
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int id = tid + 256 * i, row = id / PIECES, piece = id % PIECES;
+            *(uint4*)((char*)buf + ((long long)row * LDA * sizeof(CT)) + piece * 16) = areg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NKS; ++i) bcur[i] = bnext[i];
+        __syncthreads();
+        if (c + 1 < nchunks) load_chunk(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if constexpr (std::is_same<CT, float>::value) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const float4 a4 = *(const float4*)(buf + (mt * 16 + r) * LDA + ks * 16 + 4 * g);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, __uint_as_float(bcur[ks].x), acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, __uint_as_float(bcur[ks].y), acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, __uint_as_float(bcur[ks].z), acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, __uint_as_float(bcur[ks].w), acc[mt], 0, 0, 0);
+                }
+            } else {
+                const bf16x8 b8 = __builtin_bit_cast(bf16x8, bcur[ks]);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const bf16x8 a8 = *(const bf16x8*)(buf + (mt * 16 + r) * LDA + ks * 32 + 8 * g);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[mt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!tile_live) return;
+    const int col = nt * 16 + r;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + mt * 16 + g * 4 + i;
+            if (row >= a.M) continue;
+            float v = acc[mt][i];
+            if (a.P) {
+                a.P[((long long)blockIdx.y * a.M + row) * a.N + col] = v;
+            } else {
+                if (a.bias) v += a.bias[col];
+                v = act_dev(v, a.act);
+                if (a.c_ct) ((CT*)a.C)[(long long)row * a.ldc + col] = (CT)v;
+                else ((float*)a.C)[(long long)row * a.ldc + col] = v;
+            }
+        }
+    }
+}
+
+void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return;
+    const bool bf = a.wtype == W_BF16;
+    const int kstep = bf ? 32 : 16, ealign = bf ? 8 : 4;
+    if (a.N % 16 || a.K % kstep || a.splits <= 0 || a.K % a.splits || (a.K / a.splits) % kstep || (a.lda % ealign) || ((uintptr_t)a.A & 15))
+        throw std::runtime_error("skinny gemm: shape not tileable (N % 16, K % k-step, K % splits, lda alignment)");
+    if (!a.P && a.splits != 1) throw std::runtime_error("skinny gemm: split K needs a partial buffer");
+    dim3 grid((a.N + 63) / 64, a.splits, (a.M + 63) / 64), block(256);
+    if (bf) hipLaunchKernelGGL(skinny_gemm_kernel<__bf16>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(skinny_gemm_kernel<float>, grid, block, 0, s, a);
+}
+
+// ------------------------------------------------------------------ add & norm, one 256-thread block per row
+// Thread t owns channels 4t..4t+3 (D <= 1024).  All K-slice loads of a thread are independent 16-byte
+// loads issued together; the slices are then added in slice order, so the sum is bitwise reproducible.
+
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum4(float v, float* red, int tid) {
+    v = wsum64(v);
+    __syncthreads();  // red[] may still be read from a previous call
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void add_norm_kernel(AddNormArgs a) {
+    constexpr int MAXS = 16;
+    __shared__ float red[4];
+    const int tid = threadIdx.x, m = blockIdx.x;
+    const int c = 4 * tid;
+    const bool on = c < a.D;
+    float* __restrict__ xr = a.X + (long long)m * a.ldx;
+    const float* __restrict__ P = a.P;
+    float4 v = on ? *(const float4*)(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P) {
+        float4 part[MAXS];
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k)
+            part[k] = (on && k < a.splits) ? *(const float4*)(P + ((long long)k * a.M + m) * a.D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k) { p.x += part[k].x; p.y += part[k].y; p.z += part[k].z; p.w += part[k].w; }
+        if (on) {
+            if (a.pbias) { const float4 b4 = *(const float4*)(a.pbias + c); p.x += b4.x; p.y += b4.y; p.z += b4.z; p.w += b4.w; }
+            if (a.colscale) { const float4 s4 = *(const float4*)(a.colscale + c); p.x *= s4.x; p.y *= s4.y; p.z *= s4.z; p.w *= s4.w; }
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            *(float4*)(xr + c) = v;
+        }
+    }
+    if (a.pos && tid == 0) a.pos[m] += a.pos_delta;
+    if (!a.g) return;
+    const float mean = block_sum4((v.x + v.y) + (v.z + v.w), red, tid) / (float)a.D;
+    const float d0 = on ? v.x - mean : 0.f, d1 = on ? v.y - mean : 0.f, d2 = on ? v.z - mean : 0.f, d3 = on ? v.w - mean : 0.f;
+    const float rstd = 1.0f / sqrtf(block_sum4((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3), red, tid) / (float)a.D + a.eps);
+    float dot = 0.f;
+    if (on) {
+        const float4 g4 = *(const float4*)(a.g + c), b4 = *(const float4*)(a.b + c);
+        const float y0 = d0 * rstd * g4.x + b4.x, y1 = d1 * rstd * g4.y + b4.y, y2 = d2 * rstd * g4.z + b4.z, y3 = d3 * rstd * g4.w + b4.w;
+        if (a.H) {
+            if (a.h_ct) {
+                CT* dst = (CT*)a.H + (long long)m * a.D + c;
+                dst[0] = (CT)y0; dst[1] = (CT)y1; dst[2] = (CT)y2; dst[3] = (CT)y3;
+            } else {
+                *(float4*)((float*)a.H + (long long)m * a.D + c) = make_float4(y0, y1, y2, y3);
+            }
+        }
+        if (a.H32) *(float4*)(a.H32 + (long long)m * a.D + c) = make_float4(y0, y1, y2, y3);
+        if (a.dot_w) { const float4 w4 = *(const float4*)(a.dot_w + c); dot = (y0 * w4.x + y1 * w4.y) + (y2 * w4.z + y3 * w4.w); }
+    }
+    if (a.dot_w) {
+        dot = block_sum4(dot, red, tid);
+        if (tid == 0) a.dot_out[m] = dot + a.dot_b[0];
+    }
+}
+
+void launch_add_norm(const AddNormArgs& a, hipStream_t s) {
+    if (a.M <= 0) return;
+    if (a.D % 4 || a.D > 1024 || (a.ldx & 3)) throw std::runtime_error("add_norm: width must be a multiple of 4 and <= 1024");
+    if (a.P && (a.splits < 1 || a.splits > 16)) throw std::runtime_error("add_norm: 1..16 K-slices supported");
+    dim3 grid(a.M), block(256);
+    if (a.wtype == W_BF16) hipLaunchKernelGGL(add_norm_kernel<__bf16>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(add_norm_kernel<float>, grid, block, 0, s, a);
+}
+
+// ------------------------------------------------------------------ decode attention, one 4-wave block per (row, head)
+// The earlier keys of the slot are cut into four contiguous ranges, one per wave (the step is latency
+// bound, so more independent loads in flight matter more than work per wave).  Each wave runs a local
+// softmax over its range (lane per key for the scores, then 4 key groups x 16 channel quads for P.V) and
+// leaves (max, sum, unnormalised output) in LDS; wave 0 merges the four and adds the new token, whose
+// rotated key and value never leave registers.  Every wave rotates q itself; wave 0 appends k, v to the cache.
+template <typename CT>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int p = a.pos[m];
+    const int pc = p < a.tab_len ? p : a.tab_len - 1;
+    const float cs = a.cos_tab[(long long)pc * 32 + (lane >> 1)], sn = a.sin_tab[(long long)pc * 32 + (lane >> 1)];
+    const float* row = a.qkv + (long long)m * 3 * a.d + h * 64;
+    const float qv = row[lane], kv = row[a.d + lane], vv = row[2 * a.d + lane];
+    const float qo = __shfl_xor(qv, 1, 64), ko = __shfl_xor(kv, 1, 64);
+    // pair (2i, 2i+1): even lane x*c - y*s, odd lane x*s + y*c, with x the even and y the odd element
+    const float qr = (lane & 1) ? (qo * sn + qv * cs) : (qv * cs - qo * sn);
+    const float kr = (lane & 1) ? (ko * sn + kv * cs) : (kv * cs - ko * sn);
+    const long long cbase = (long long)(a.slot0 + m) * a.cap * a.d + h * 64;
+    if (w == 0) {
+        a.kcache[cbase + (long long)(p % a.cap) * a.d + lane] = kr;
+        a.vcache[cbase + (long long)(p % a.cap) * a.d + lane] = vv;
+    }
+    int j0 = 0;
+    if (a.window > 0 && p - a.window + 1 > 0) j0 = p - a.window + 1;
+    const int nk = p - j0;                    // earlier keys only
+    const int chunk = ((nk + 3) / 4 + 3) & ~3; // keys per wave, multiple of 4
+    const int kb = w * chunk, ke = min(nk, kb + chunk), cnt = max(ke - kb, 0);
+    const int scap = (a.cap / 4 + 8) & ~3;
+    float* qs = smem + (long long)w * (64 + scap);
+    float* sc = qs + 64;
+    float* comb = smem + 4ll * (64 + scap);   // [4][68]: max, sum, pad, pad, out[64]
+    qs[lane] = qr;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float4 q[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) q[i] = *(const float4*)(qs + 4 * i);
+    const float* kc = a.kcache + cbase;
+    const float* vc = a.vcache + cbase;
+    float mx = -INFINITY;
+    for (int j = lane; j < cnt; j += 64) {
+        const float* kr_ = kc + (long long)((j0 + kb + j) % a.cap) * a.d;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 k4 = *(const float4*)(kr_ + 4 * i);
+            s0 += q[i].x * k4.x; s1 += q[i].y * k4.y; s2 += q[i].z * k4.z; s3 += q[i].w * k4.w;
+        }
+        const float sv = ((s0 + s1) + (s2 + s3)) * 0.125f;
+        sc[j] = sv;
+        mx = fmaxf(mx, sv);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int j = lane; j < cnt; j += 64) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = wsum64(sum);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int kg = lane >> 4, cq = lane & 15;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j = kg;
+    for (; j + 12 < cnt; j += 16) {
+        const float4 v0 = *(const float4*)(vc + (long long)((j0 + kb + j) % a.cap) * a.d + 4 * cq);
+        const float4 v1 = *(const float4*)(vc + (long long)((j0 + kb + j + 4) % a.cap) * a.d + 4 * cq);
+        const float4 v2 = *(const float4*)(vc + (long long)((j0 + kb + j + 8) % a.cap) * a.d + 4 * cq);
+        const float4 v3 = *(const float4*)(vc + (long long)((j0 + kb + j + 12) % a.cap) * a.d + 4 * cq);
+        const float p0 = sc[j], p1 = sc[j + 4], p2 = sc[j + 8], p3 = sc[j + 12];
+        o.x += (p0 * v0.x + p1 * v1.x) + (p2 * v2.x + p3 * v3.x);
+        o.y += (p0 * v0.y + p1 * v1.y) + (p2 * v2.y + p3 * v3.y);
+        o.z += (p0 * v0.z + p1 * v1.z) + (p2 * v2.z + p3 * v3.z);
+        o.w += (p0 * v0.w + p1 * v1.w) + (p2 * v2.w + p3 * v3.w);
+    }
+    for (; j < cnt; j += 4) {
+        const float4 v0 = *(const float4*)(vc + (long long)((j0 + kb + j) % a.cap) * a.d + 4 * cq);
+        const float p0 = sc[j];
+        o.x += p0 * v0.x; o.y += p0 * v0.y; o.z += p0 * v0.z; o.w += p0 * v0.w;
+    }
+    o.x += __shfl_xor(o.x, 16, 64); o.y += __shfl_xor(o.y, 16, 64); o.z += __shfl_xor(o.z, 16, 64); o.w += __shfl_xor(o.w, 16, 64);
+    o.x += __shfl_xor(o.x, 32, 64); o.y += __shfl_xor(o.y, 32, 64); o.z += __shfl_xor(o.z, 32, 64); o.w += __shfl_xor(o.w, 32, 64);
+    float* cw = comb + w * 68;
+    if (lane == 0) { cw[0] = mx; cw[1] = sum; }
+    if (kg == 0) *(float4*)(cw + 4 + 4 * cq) = o;
+    __syncthreads();
+    if (w != 0) return;
+    // merge: lane e owns channel e again
+    const float s_new = wsum64(qr * kr) * 0.125f;
+    float M = s_new;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) M = fmaxf(M, comb[i * 68]);
+    float tot = expf(s_new - M), acc = tot * vv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float mi = comb[i * 68];
+        const float f = mi == -INFINITY ? 0.f : expf(mi - M);
+        tot += comb[i * 68 + 1] * f;
+        acc += comb[i * 68 + 4 + lane] * f;
+    }
+    const float out = acc / tot;
+    if (a.out_ct) ((CT*)a.out)[(long long)m * a.d + h * 64 + lane] = (CT)out;
+    else ((float*)a.out)[(long long)m * a.d + h * 64 + lane] = out;
+}
+
+void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
+    if (a.M <= 0) return;
+    if (a.d != a.heads * 64) throw std::runtime_error("attention: head dimension must be 64");
+    const int scap = (a.cap / 4 + 8) & ~3;
+    const size_t smem = ((size_t)4 * (64 + scap) + 4 * 68) * sizeof(float);
+    if (smem > 64 * 1024) throw std::runtime_error("attention: context capacity too large for the LDS score buffer");
+    dim3 grid((unsigned)(a.M * a.heads)), block(256);
+    if (a.wtype == W_BF16) hipLaunchKernelGGL(attn_decode_kernel<__bf16>, grid, block, smem, s, a);
+    else hipLaunchKernelGGL(attn_decode_kernel<float>, grid, block, smem, s, a);
+}
+
+}  // namespace ptts

@@ -160,6 +160,11 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     };
     flow_in_packed = packed("flow.in_proj.w");
     flow_out_packed = packed("flow.final.lin.w");
+    flow_cond_packed = packed("flow.cond.w");
+    for (int i = 0; i < s.lm_layers; ++i) {
+        std::string p = "lm.l" + std::to_string(i) + ".";
+        lm_packed.push_back(PackedLayer{packed(p + "qkv.w"), packed(p + "out.w"), packed(p + "ff1.w"), packed(p + "ff2.w")});
+    }
     std::vector<const void*> tab(static_cast<size_t>(6) * nb);
     for (int i = 0; i < nb; ++i) {
         std::string p = "flow.b" + std::to_string(i) + ".";
@@ -565,22 +570,77 @@ void Engine::lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* 
     for (int i = 0; i < nb; ++i) b.lm_pos_host[slot0 + i] += adv_host ? adv_host[i] : rpb;
 }
 
+// K-slices for a split-K product: about 256 deep each, at most 16, dividing K into k-step multiples.
+static int pick_splits(int K, int kstep) {
+    int s = K / 256;
+    if (s < 1) s = 1;
+    if (s > 16) s = 16;
+    while (s > 1 && (K % s != 0 || (K / s) % kstep != 0)) --s;
+    return s;
+}
+
 // sequence[B][latent] (NaN = BOS) -> conditioning[B][d_model], eos[B]   (src/pocket_tts.cpp:323-411, decode shape)
+// One new row per utterance.  Per layer: QKV product -> rotate/append/attend -> output product as K-slices ->
+// add & norm -> FFN-1 product with GELU -> FFN-2 product as K-slices -> add & norm (which also produces the
+// next layer's normalised input, or after the last layer the conditioning vector and the EOS logit).
 void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev) {
     const Spec& s = spec();
+    const int B = b.B, D = s.d_model, F = s.lm_ffn;
+    const int wt = model_->flow_wtype, ct = wt == W_BF16 ? 1 : 0, kstep = wt == W_BF16 ? 32 : 16;
+    for (int i = 0; i < B; ++i)
+        if (b.lm_pos_host[i] + 1 > b.lm_cap) throw std::runtime_error("LM context exceeds the KV-cache capacity (voice + text + frames too long)");
     phase_begin(0);
-    launch_prep_latent(seq_dev, b.seq_in.f(), b.B, s.latent, 0, hd_.bos, nullptr, stream_);
+    launch_prep_latent(seq_dev, b.seq_in.f(), B, s.latent, 0, hd_.bos, nullptr, stream_);
     const DevWeight& win = hd_.lm_in;
     GemmArgs g;
-    g.A = b.seq_in.f(); g.lda = s.latent; g.W = win.p; g.wtype = win.wtype; g.C = b.x.f(); g.ldc = s.d_model;
-    g.M = b.B; g.N = s.d_model; g.K = s.latent;
+    g.A = b.seq_in.f(); g.lda = s.latent; g.W = win.p; g.wtype = win.wtype; g.C = b.x.f(); g.ldc = D;
+    g.M = B; g.N = D; g.K = s.latent;
     launch_gemm(g, stream_);
-    lm_rows(b, 0, b.B, 1, b.x.f());
-    LayerNormArgs ln;
-    ln.X = b.x.f(); ln.ldx = s.d_model; ln.Y = cond_dev; ln.ldy = s.d_model; ln.M = b.B; ln.D = s.d_model;
-    ln.g = hd_.out_g; ln.b = hd_.out_b; ln.eps = s.lm_eps;
-    launch_layernorm(ln, stream_);
-    launch_rowdot(cond_dev, s.d_model, b.B, s.d_model, hd_.eos_w, hd_.eos_b, eos_dev, stream_);
+    const int s_out = pick_splits(D, kstep), s_ff2 = pick_splits(F, kstep);
+    const size_t pneed = static_cast<size_t>(std::max(s_out, s_ff2)) * B * D * 4;
+    if (b.partial.bytes < pneed) b.partial.alloc(pneed);
+    AddNormArgs an;
+    an.X = b.x.f(); an.ldx = D; an.M = B; an.D = D; an.wtype = wt; an.eps = s.lm_eps;
+    an.g = hd_.lm[0].ln1g; an.b = hd_.lm[0].ln1b; an.H = b.h.p; an.h_ct = ct;
+    launch_add_norm(an, stream_);
+    const long long layer_stride = static_cast<long long>(B) * b.lm_cap * D;
+    for (int l = 0; l < s.lm_layers; ++l) {
+        const TfLayer& w = hd_.lm[l];
+        const Model::PackedLayer& pw = model_->lm_packed[l];
+        SkinnyArgs q;
+        q.A = b.h.p; q.lda = D; q.Wp = pw.qkv; q.wtype = wt; q.M = B; q.N = 3 * D; q.K = D; q.C = b.qkv.p; q.ldc = 3 * D;
+        launch_skinny_gemm(q, stream_);
+        AttnDecodeArgs at;
+        at.qkv = b.qkv.f(); at.kcache = b.lm_k.f() + l * layer_stride; at.vcache = b.lm_v.f() + l * layer_stride;
+        at.pos = b.lm_pos.as<int>(); at.M = B; at.d = D; at.heads = s.lm_heads; at.cap = b.lm_cap; at.window = 0;
+        at.cos_tab = model_->lm_cos; at.sin_tab = model_->lm_sin; at.tab_len = model_->lm_tab_len;
+        at.out = b.att.p; at.out_ct = ct; at.wtype = wt;
+        launch_attn_decode(at, stream_);
+        SkinnyArgs o;
+        o.A = b.att.p; o.lda = D; o.Wp = pw.out; o.wtype = wt; o.M = B; o.N = D; o.K = D; o.splits = s_out; o.P = b.partial.f();
+        launch_skinny_gemm(o, stream_);
+        AddNormArgs a1 = an;
+        a1.P = b.partial.f(); a1.splits = s_out; a1.colscale = w.ls1; a1.g = w.ln2g; a1.b = w.ln2b;
+        launch_add_norm(a1, stream_);
+        SkinnyArgs f1;
+        f1.A = b.h.p; f1.lda = D; f1.Wp = pw.ff1; f1.wtype = wt; f1.M = B; f1.N = F; f1.K = D; f1.act = ACT_GELU;
+        f1.C = b.ff.p; f1.ldc = F; f1.c_ct = ct;
+        launch_skinny_gemm(f1, stream_);
+        SkinnyArgs f2;
+        f2.A = b.ff.p; f2.lda = F; f2.Wp = pw.ff2; f2.wtype = wt; f2.M = B; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.partial.f();
+        launch_skinny_gemm(f2, stream_);
+        AddNormArgs a2 = an;
+        a2.P = b.partial.f(); a2.splits = s_ff2; a2.colscale = w.ls2;
+        if (l + 1 < s.lm_layers) {
+            a2.g = hd_.lm[l + 1].ln1g; a2.b = hd_.lm[l + 1].ln1b;
+        } else {
+            a2.g = hd_.out_g; a2.b = hd_.out_b; a2.H32 = cond_dev;
+            a2.dot_w = hd_.eos_w; a2.dot_b = hd_.eos_b; a2.dot_out = eos_dev;
+            a2.pos = b.lm_pos.as<int>(); a2.pos_delta = 1;
+        }
+        launch_add_norm(a2, stream_);
+    }
+    for (int i = 0; i < B; ++i) b.lm_pos_host[i] += 1;
     phase_end(0);
 }
 

@@ -52,6 +52,10 @@ public:
     const float* const* d_b_fc1 = nullptr; const float* const* d_b_fc2 = nullptr;
     const float* const* d_ln_g = nullptr; const float* const* d_ln_b = nullptr;
     const void *flow_in_packed = nullptr, *flow_out_packed = nullptr;  // fragment-major flow.in_proj.w / flow.final.lin.w
+    // fragment-major copies of the weights the batched decode step streams (decode_kernels.hip)
+    struct PackedLayer { const void *qkv, *out, *ff1, *ff2; };
+    std::vector<PackedLayer> lm_packed;
+    const void* flow_cond_packed = nullptr;
     int flow_wtype = W_F32;
 
     void build_rope_tables(int lm_len, int mimi_len);
@@ -217,6 +221,7 @@ public:
     TfScratch scratch() const { return TfScratch{h.f(), qkv.f(), q.f(), att.f(), ff.f()}; }
     // flow scratch
     DevBuf cemb, ymod, mods;
+    DevBuf partial;   // split-K slabs of the decode step [splits][B][d_model] f32
     // audio out
     DevBuf audio;
     // staged inputs / outputs of a whole batch (Engine::stage / run_staged)

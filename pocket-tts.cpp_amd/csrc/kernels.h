@@ -123,6 +123,47 @@ void launch_flow_head(const FlowHeadArgs& a, hipStream_t s);
 // Host-side reorder of a flow-head weight W[N][K] into the fragment-major layout the kernel streams.
 std::vector<unsigned char> pack_flow_weight(const float* W, int N, int K, int wtype);
 
+// ---- batched decode step (decode_kernels.hip) -----------------------------------------------------
+// C[M][N] = A[M][K] * W^T with A already in the compute type (f32 or bf16) and W fragment-major
+// (pack_flow_weight layout).  splits == 1 and P == null: C = act(acc + bias) stored as f32 or compute
+// type.  P != null: K is cut into `splits` slices and slice s writes the raw f32 slab P[s][M][N].
+struct SkinnyArgs {
+    const void* A = nullptr; int lda = 0;
+    const void* Wp = nullptr; int wtype = W_F32;
+    int M = 0, N = 0, K = 0, splits = 1;
+    const float* bias = nullptr; int act = ACT_NONE;
+    void* C = nullptr; int ldc = 0; int c_ct = 0;
+    float* P = nullptr;
+};
+void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s);
+
+// Per row m: X[m] += colscale * (sum_s P[s][m] + pbias)  (skipped when P is null), then
+// y = LayerNorm(X[m]; g, b) -> H (compute type or f32), optional f32 copy H32, optional dot_out[m] = y . dot_w + dot_b,
+// optional pos[m] += pos_delta.  g == null: no normalisation outputs.
+struct AddNormArgs {
+    float* X = nullptr; int ldx = 0;
+    const float* P = nullptr; int splits = 0;
+    const float* colscale = nullptr; const float* pbias = nullptr;
+    const float* g = nullptr; const float* b = nullptr; float eps = 1e-5f;
+    void* H = nullptr; int h_ct = 0; float* H32 = nullptr;
+    const float* dot_w = nullptr; const float* dot_b = nullptr; float* dot_out = nullptr;
+    int* pos = nullptr; int pos_delta = 0;
+    int M = 0, D = 0; int wtype = W_F32;
+};
+void launch_add_norm(const AddNormArgs& a, hipStream_t s);
+
+// One new token per row: rotate q/k of qkv[M][3d] at position pos[m], append k/v to slot slot0+m of the
+// cache, attend over the slot's keys (window as in AttentionArgs), write out[M][d].
+struct AttnDecodeArgs {
+    const float* qkv = nullptr;
+    float* kcache = nullptr; float* vcache = nullptr;
+    const int* pos = nullptr; int slot0 = 0;
+    int M = 0, d = 0, heads = 0, cap = 0, window = 0;
+    const float* cos_tab = nullptr; const float* sin_tab = nullptr; int tab_len = 0;
+    void* out = nullptr; int out_ct = 0; int wtype = W_F32;
+};
+void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
+
 // Y[j][b][:] = silu(te[j][:] + cemb[b][:])   (input rows of the stacked adaLN GEMM)
 void launch_flow_mod_input(const float* te, const float* cemb, float* Y, int steps, int B, int C, hipStream_t s);
 

@@ -138,16 +138,32 @@ __global__ __launch_bounds__(256) void attention_kernel(AttentionArgs a) {
     sum = wave_sum(sum);
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS scores written by other lanes of this wave
     __builtin_amdgcn_wave_barrier();
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-    int j = 0;
-    for (; j + 4 <= nk; j += 4) {
-        o0 += sc[j] * vc[(long long)((j0 + j) % a.cap) * a.d + lane];
-        o1 += sc[j + 1] * vc[(long long)((j0 + j + 1) % a.cap) * a.d + lane];
-        o2 += sc[j + 2] * vc[(long long)((j0 + j + 2) % a.cap) * a.d + lane];
-        o3 += sc[j + 3] * vc[(long long)((j0 + j + 3) % a.cap) * a.d + lane];
+    // P.V with the wave split into 4 key groups x 16 channel quads (four keys in flight per lane)
+    const int kg = lane >> 4, cq = lane & 15;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j = kg;
+    for (; j + 12 < nk; j += 16) {
+        const float4 v0 = *(const float4*)(vc + (long long)((j0 + j) % a.cap) * a.d + 4 * cq);
+        const float4 v1 = *(const float4*)(vc + (long long)((j0 + j + 4) % a.cap) * a.d + 4 * cq);
+        const float4 v2 = *(const float4*)(vc + (long long)((j0 + j + 8) % a.cap) * a.d + 4 * cq);
+        const float4 v3 = *(const float4*)(vc + (long long)((j0 + j + 12) % a.cap) * a.d + 4 * cq);
+        const float p0 = sc[j], p1 = sc[j + 4], p2 = sc[j + 8], p3 = sc[j + 12];
+        o.x += (p0 * v0.x + p1 * v1.x) + (p2 * v2.x + p3 * v3.x);
+        o.y += (p0 * v0.y + p1 * v1.y) + (p2 * v2.y + p3 * v3.y);
+        o.z += (p0 * v0.z + p1 * v1.z) + (p2 * v2.z + p3 * v3.z);
+        o.w += (p0 * v0.w + p1 * v1.w) + (p2 * v2.w + p3 * v3.w);
     }
-    for (; j < nk; ++j) o0 += sc[j] * vc[(long long)((j0 + j) % a.cap) * a.d + lane];
-    if (live) a.out[(long long)m * a.d + h * 64 + lane] = ((o0 + o1) + (o2 + o3)) / sum;
+    for (; j < nk; j += 4) {
+        const float4 v0 = *(const float4*)(vc + (long long)((j0 + j) % a.cap) * a.d + 4 * cq);
+        const float p0 = sc[j];
+        o.x += p0 * v0.x; o.y += p0 * v0.y; o.z += p0 * v0.z; o.w += p0 * v0.w;
+    }
+    o.x += __shfl_xor(o.x, 16, 64); o.y += __shfl_xor(o.y, 16, 64); o.z += __shfl_xor(o.z, 16, 64); o.w += __shfl_xor(o.w, 16, 64);
+    o.x += __shfl_xor(o.x, 32, 64); o.y += __shfl_xor(o.y, 32, 64); o.z += __shfl_xor(o.z, 32, 64); o.w += __shfl_xor(o.w, 32, 64);
+    if (live && kg == 0) {
+        const float inv = 1.0f / sum;
+        *(float4*)(a.out + (long long)m * a.d + h * 64 + 4 * cq) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+    }
 }
 
 void launch_attention(const AttentionArgs& a, hipStream_t s) {

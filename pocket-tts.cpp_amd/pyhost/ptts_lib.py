@@ -52,6 +52,8 @@ EXT_SYMBOLS = [
     "pocket_tts_tokenize", "ptts_text_conditioner", "ptts_state_new", "ptts_state_free", "ptts_state_reset",
     "ptts_lm_prefill", "ptts_lm_step", "ptts_flow_euler", "ptts_mimi_decode", "ptts_mimi_encode",
     "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes",
+    "ptts_tokenizer_new", "ptts_tokenizer_free", "ptts_tokenizer_vocab", "ptts_tokenizer_encode",
+    "ptts_audio_load_wav", "ptts_audio_save_wav", "ptts_audio_resample", "ptts_audio_normalize",
 ]
 
 _lib = None
@@ -109,8 +111,80 @@ def load() -> C.CDLL:
     L.ptts_phase_timing.restype = ci; L.ptts_phase_timing.argtypes = [vp, ci]
     L.ptts_phase_times.restype = ci; L.ptts_phase_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.ptts_weight_bytes.restype = ci; L.ptts_weight_bytes.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    L.ptts_tokenizer_new.restype = vp; L.ptts_tokenizer_new.argtypes = [cp]
+    L.ptts_tokenizer_free.restype = None; L.ptts_tokenizer_free.argtypes = [vp]
+    L.ptts_tokenizer_vocab.restype = ci; L.ptts_tokenizer_vocab.argtypes = [vp]
+    L.ptts_tokenizer_encode.restype = ci; L.ptts_tokenizer_encode.argtypes = [vp, cp, ci, i64p, ci]
+    L.ptts_audio_load_wav.restype = ci; L.ptts_audio_load_wav.argtypes = [cp, ci, f32p, ci]
+    L.ptts_audio_save_wav.restype = ci; L.ptts_audio_save_wav.argtypes = [cp, f32p, ci, ci]
+    L.ptts_audio_resample.restype = ci; L.ptts_audio_resample.argtypes = [f32p, ci, ci, ci, f32p, ci]
+    L.ptts_audio_normalize.restype = ci; L.ptts_audio_normalize.argtypes = [f32p, ci, f32p]
     _lib = L
     return L
+
+
+class Tokenizer:
+    """Host-side text pre-step (no GPU needed)."""
+
+    def __init__(self, model_path: str):
+        self.L = load()
+        self.p = self.L.ptts_tokenizer_new(model_path.encode())
+        if not self.p:
+            raise PttsError(f"tokenizer: {last_error()}")
+
+    def vocab(self) -> int:
+        return self.L.ptts_tokenizer_vocab(self.p)
+
+    def encode(self, text: str, raw: bool = False) -> List[int]:
+        buf = np.zeros(4096, np.int64)
+        n = self.L.ptts_tokenizer_encode(self.p, text.encode("utf-8"), 1 if raw else 0, buf, len(buf))
+        if n < 0:
+            raise PttsError(last_error())
+        return buf[:n].tolist()
+
+    def close(self):
+        if self.p:
+            self.L.ptts_tokenizer_free(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def audio_resample(x, in_rate: int, out_rate: int) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    cap = int(np.ceil(len(x) * out_rate / in_rate)) + 8
+    out = np.empty(cap, np.float32)
+    n = load().ptts_audio_resample(x, len(x), in_rate, out_rate, out, cap)
+    if n < 0:
+        raise PttsError(last_error())
+    return out[:n].copy()
+
+
+def audio_normalize(x) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(max(len(x), 1), np.float32)
+    n = load().ptts_audio_normalize(x, len(x), out)
+    if n < 0:
+        raise PttsError(last_error())
+    return out[:n].copy()
+
+
+def audio_load_wav(path: str, target_rate: int = 24000, cap: int = 1 << 24) -> np.ndarray:
+    out = np.empty(cap, np.float32)
+    n = load().ptts_audio_load_wav(path.encode(), target_rate, out, cap)
+    if n < 0:
+        raise PttsError(last_error())
+    return out[:n].copy()
+
+
+def audio_save_wav(path: str, x, rate: int = 24000) -> None:
+    x = np.ascontiguousarray(x, np.float32)
+    if load().ptts_audio_save_wav(path.encode(), x, len(x), rate) < 0:
+        raise PttsError(last_error())
 
 
 def last_error() -> str:
