@@ -298,6 +298,8 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     scratch_rows_d = xe;
     scratch_rows_f = std::max(rows_lm * s.lm_ffn, rows_dec * s.mimi_ffn);
     ff.alloc(scratch_rows_f * 4);
+    dx.alloc(rows_dec * M * 4); dh.alloc(rows_dec * M * 4); dq.alloc(rows_dec * M * 4); datt.alloc(rows_dec * M * 4);
+    dqkv.alloc(rows_dec * M * 3 * 4); dff.alloc(rows_dec * s.mimi_ffn * 4);
     st_nv.alloc(static_cast<size_t>(B) * 4); st_nt.alloc(static_cast<size_t>(B) * 4); st_len.alloc(static_cast<size_t>(B) * 4);
     (void)dmax; (void)fmax;
     seq_in.alloc(static_cast<size_t>(B) * L * 4);
@@ -379,6 +381,9 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
     if (opt_.device < 0 || opt_.device >= ndev) throw std::runtime_error("engine: device ordinal out of range");
     PTTS_HIP(hipSetDevice(opt_.device));
     PTTS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    PTTS_HIP(hipStreamCreateWithFlags(&dec_stream_, hipStreamNonBlocking));
+    PTTS_HIP(hipEventCreateWithFlags(&latents_ready_, hipEventDisableTiming));
+    PTTS_HIP(hipEventCreateWithFlags(&dec_done_, hipEventDisableTiming));
     Pack pack(opt_.pack_path);
     model_ = std::make_unique<Model>(pack, opt_.precision);
     const Spec& s = model_->spec();
@@ -456,28 +461,34 @@ Engine::~Engine() {
     for (auto& pe : pending_events_) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
     if (ev_[0]) (void)hipEventDestroy(ev_[0]);
     if (ev_[1]) (void)hipEventDestroy(ev_[1]);
+    if (latents_ready_) (void)hipEventDestroy(latents_ready_);
+    if (dec_done_) (void)hipEventDestroy(dec_done_);
+    if (dec_stream_) { (void)hipStreamSynchronize(dec_stream_); (void)hipStreamDestroy(dec_stream_); }
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
 void Engine::enable_phase_timing(bool on) { timing_ = on; times_ = PhaseTimes(); }
 
-void Engine::phase_begin(int which) {
+void Engine::phase_begin(int which, hipStream_t st) {
     if (!timing_) return;
+    if (!st) st = stream_;
     hipEvent_t a, b;
     PTTS_HIP(hipEventCreate(&a));
     PTTS_HIP(hipEventCreate(&b));
-    PTTS_HIP(hipEventRecord(a, stream_));
+    PTTS_HIP(hipEventRecord(a, st));
     pending_events_.push_back({which, {a, b}});
 }
 
-void Engine::phase_end(int which) {
+void Engine::phase_end(int which, hipStream_t st) {
     if (!timing_) return;
+    if (!st) st = stream_;
     for (auto it = pending_events_.rbegin(); it != pending_events_.rend(); ++it)
-        if (it->first == which) { PTTS_HIP(hipEventRecord(it->second.second, stream_)); return; }
+        if (it->first == which) { PTTS_HIP(hipEventRecord(it->second.second, st)); return; }
 }
 
 Engine::PhaseTimes Engine::phase_times() {
     PTTS_HIP(hipStreamSynchronize(stream_));
+    PTTS_HIP(hipStreamSynchronize(dec_stream_));
     for (auto& pe : pending_events_) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) {
@@ -513,35 +524,35 @@ Batch* Engine::acquire_batch(int B) {
 void Engine::transformer(const std::vector<TfLayer>& layers, float* kc, float* vc, long long layer_stride, int cap,
                          const int* pos_dev, int slot0, int nb, int rpb, float* X, int d, int heads, int ffn, float eps,
                          int window, const float* cos_tab, const float* sin_tab, int tab_len, const TfScratch& b, float* last_out,
-                         long long last_bs, int last_ld) {
+                         long long last_bs, int last_ld, hipStream_t st) {
     const int M = nb * rpb;
     for (size_t l = 0; l < layers.size(); ++l) {
         const TfLayer& w = layers[l];
         LayerNormArgs ln;
         ln.X = X; ln.ldx = d; ln.Y = b.h; ln.ldy = d; ln.M = M; ln.D = d; ln.g = w.ln1g; ln.b = w.ln1b; ln.eps = eps;
-        launch_layernorm(ln, stream_);
+        launch_layernorm(ln, st);
         GemmArgs g;
         g.A = b.h; g.lda = d; g.W = w.qkv.p; g.wtype = w.qkv.wtype; g.C = b.qkv; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d;
-        launch_gemm(g, stream_);
+        launch_gemm(g, st);
         RopeAppendArgs r;
         r.qkv = b.qkv; r.q_out = b.q; r.kcache = kc + l * layer_stride; r.vcache = vc + l * layer_stride;
         r.pos = pos_dev; r.slot0 = slot0; r.rpb = rpb; r.M = M; r.d = d; r.heads = heads; r.cap = cap;
         r.cos_tab = cos_tab; r.sin_tab = sin_tab; r.tab_len = tab_len;
-        launch_rope_append(r, stream_);
+        launch_rope_append(r, st);
         AttentionArgs at;
         at.q = b.q; at.out = b.att; at.kcache = r.kcache; at.vcache = r.vcache; at.pos = pos_dev; at.slot0 = slot0; at.rpb = rpb;
         at.M = M; at.d = d; at.heads = heads; at.cap = cap; at.window = window;
-        launch_attention(at, stream_);
+        launch_attention(at, st);
         GemmArgs o;
         o.A = b.att; o.lda = d; o.W = w.out.p; o.wtype = w.out.wtype; o.C = X; o.ldc = d; o.R = X; o.ldr = d; o.colscale = w.ls1;
         o.M = M; o.N = d; o.K = d;
-        launch_gemm(o, stream_);
+        launch_gemm(o, st);
         ln.g = w.ln2g; ln.b = w.ln2b;
-        launch_layernorm(ln, stream_);
+        launch_layernorm(ln, st);
         GemmArgs f1;
         f1.A = b.h; f1.lda = d; f1.W = w.ff1.p; f1.wtype = w.ff1.wtype; f1.C = b.ff; f1.ldc = ffn; f1.act_pre = ACT_GELU;
         f1.M = M; f1.N = ffn; f1.K = d;
-        launch_gemm(f1, stream_);
+        launch_gemm(f1, st);
         GemmArgs f2;
         f2.A = b.ff; f2.lda = ffn; f2.W = w.ff2.p; f2.wtype = w.ff2.wtype; f2.R = X; f2.ldr = d; f2.colscale = w.ls2;
         f2.M = M; f2.N = d; f2.K = ffn;
@@ -550,7 +561,7 @@ void Engine::transformer(const std::vector<TfLayer>& layers, float* kc, float* v
             f2.r_bs = (long long)rpb * d; f2.a_bs = (long long)rpb * ffn;
         }
         else { f2.C = X; f2.ldc = d; }
-        launch_gemm(f2, stream_);
+        launch_gemm(f2, st);
     }
 }
 
@@ -564,7 +575,7 @@ void Engine::lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* 
     const auto& layers = hd_.lm;
     const long long layer_stride = static_cast<long long>(b.B) * b.lm_cap * s.d_model;
     transformer(layers, b.lm_k.f(), b.lm_v.f(), layer_stride, b.lm_cap, b.lm_pos.as<int>() + slot0, slot0, nb, rpb, X, s.d_model,
-                s.lm_heads, s.lm_ffn, s.lm_eps, 0, model_->lm_cos, model_->lm_sin, model_->lm_tab_len, b.scratch(), nullptr, 0, 0);
+                s.lm_heads, s.lm_ffn, s.lm_eps, 0, model_->lm_cos, model_->lm_sin, model_->lm_tab_len, b.scratch(), nullptr, 0, 0, stream_);
     if (adv_dev) launch_advance_pos_vec(b.lm_pos.as<int>() + slot0, adv_dev, nb, stream_);
     else launch_advance_pos(b.lm_pos.as<int>() + slot0, nb, rpb, stream_);
     for (int i = 0; i < nb; ++i) b.lm_pos_host[slot0 + i] += adv_host ? adv_host[i] : rpb;
@@ -671,30 +682,30 @@ void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long
 
 // latent rows (batched mapping: utterance b at lat_dev + b*lat_bs, n rows of `latent` floats)
 // -> audio[b][n*frame]   (src/pocket_tts.cpp:454-546 for one chunk of n <= 15 frames)
-void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs) {
+void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs, hipStream_t st) {
     const Spec& s = spec();
     if (n <= 0 || n > kDecChunk) throw std::runtime_error("decoder chunk must hold 1..15 frames");
     const int B = b.B, L = s.latent, M = s.mimi_dim, U = s.upsample;
     const int T0 = n * U, T0max = kDecChunk * U;
     if (b.dec_pos_host + T0 > model_->mimi_tab_len) throw std::runtime_error("decoder position exceeds the rotary table");
-    phase_begin(2);
+    phase_begin(2, st);
     // gather the chunk's latent rows and de-normalise them
     PTTS_HIP(hipMemcpy2DAsync(b.zbuf.p, static_cast<size_t>(n) * L * 4, lat_dev, static_cast<size_t>(lat_bs) * 4,
-                              static_cast<size_t>(n) * L * 4, B, hipMemcpyDeviceToDevice, stream_));
-    launch_prep_latent(b.zbuf.f(), b.zbuf.f(), B * n, L, 1, hd_.emb_std, hd_.emb_mean, stream_);
+                              static_cast<size_t>(n) * L * 4, B, hipMemcpyDeviceToDevice, st));
+    launch_prep_latent(b.zbuf.f(), b.zbuf.f(), B * n, L, 1, hd_.emb_std, hd_.emb_mean, st);
     const DevWeight& wi = hd_.dec_in;
     GemmArgs g;
     g.A = b.zbuf.f(); g.lda = L; g.W = wi.p; g.wtype = wi.wtype; g.M = B * n; g.N = M; g.K = L; g.rpb = n;
     g.a_bs = static_cast<long long>(n) * L;
     g.C = b.qbuf.f() + M; g.c_bs = static_cast<long long>(1 + kDecChunk) * M; g.ldc = M;
-    launch_gemm(g, stream_);
-    launch_upsample_dw(b.qbuf.f(), static_cast<long long>(1 + kDecChunk) * M, n, M, U, hd_.dec_up_w, b.x.f(), B, stream_);
+    launch_gemm(g, st);
+    launch_upsample_dw(b.qbuf.f(), static_cast<long long>(1 + kDecChunk) * M, n, M, U, hd_.dec_up_w, b.dx.f(), B, st);
     const int H0 = s.kernel - 1;
     const auto& layers = hd_.dec;
     const long long ybs = static_cast<long long>(H0 + T0max) * M;
     transformer(layers, b.dec_k.f(), b.dec_v.f(), static_cast<long long>(B) * b.dec_cap * M, b.dec_cap, b.dec_pos.as<int>(), 0, B, T0,
-                b.x.f(), M, s.mimi_heads, s.mimi_ffn, s.mimi_eps, s.mimi_context, model_->mimi_cos, model_->mimi_sin,
-                model_->mimi_tab_len, b.scratch(), b.ybuf.f() + static_cast<long long>(H0) * M, ybs, M);
+                b.dx.f(), M, s.mimi_heads, s.mimi_ffn, s.mimi_eps, s.mimi_context, model_->mimi_cos, model_->mimi_sin,
+                model_->mimi_tab_len, b.dec_scratch(), b.ybuf.f() + static_cast<long long>(H0) * M, ybs, M, st);
     // SEANet decoder
     int c = 8 * s.n_filters;
     {
@@ -703,7 +714,7 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
         a.A = b.ybuf.f(); a.a_bs = ybs; a.lda = M; a.rpb = T0; a.W = w.p; a.wtype = w.wtype; a.bias = hd_.dec_conv0_b;
         a.M = B * T0; a.N = c; a.K = s.kernel * M;
         a.C = b.e0buf.f() + c; a.c_bs = static_cast<long long>(1 + T0max) * c; a.ldc = c; a.c_act = ACT_ELU;
-        launch_gemm(a, stream_);
+        launch_gemm(a, st);
     }
     const float* prev = b.e0buf.f();
     long long prev_bs = static_cast<long long>(1 + T0max) * c;
@@ -718,39 +729,39 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
         up.C = b.ubuf[i].f(); up.c_bs = static_cast<long long>(T2max) * co; up.ldc = r * co;
         up.C2 = b.uebuf[i].f() + static_cast<long long>(rk - 1) * co; up.c2_bs = static_cast<long long>(rk - 1 + T2max) * co;
         up.ldc2 = r * co; up.c2_act = ACT_ELU;
-        launch_gemm(up, stream_);
+        launch_gemm(up, st);
         GemmArgs c1;
         c1.A = b.uebuf[i].f(); c1.a_bs = up.c2_bs; c1.lda = co; c1.rpb = T2; c1.W = w1.p; c1.wtype = w1.wtype;
         c1.bias = hd_.dec_c1_b[i]; c1.M = B * T2; c1.N = co / 2; c1.K = rk * co;
         c1.C = b.h1buf[i].f(); c1.c_bs = static_cast<long long>(T2max) * (co / 2); c1.ldc = co / 2; c1.c_act = ACT_ELU;
-        launch_gemm(c1, stream_);
+        launch_gemm(c1, st);
         GemmArgs c2;
         c2.A = b.h1buf[i].f(); c2.a_bs = c1.c_bs; c2.lda = co / 2; c2.rpb = T2; c2.W = w2.p; c2.wtype = w2.wtype;
         c2.bias = hd_.dec_c2_b[i]; c2.M = B * T2; c2.N = co; c2.K = co / 2;
         c2.R = b.ubuf[i].f(); c2.r_bs = up.c_bs; c2.ldr = co;
         c2.C = b.ebuf[i].f() + static_cast<long long>(hn) * co; c2.c_bs = static_cast<long long>(hn + T2max) * co; c2.ldc = co;
         c2.c_act = ACT_ELU;
-        launch_gemm(c2, stream_);
+        launch_gemm(c2, st);
         prev = b.ebuf[i].f(); prev_bs = c2.c_bs;
         c = co; T = T2; Tmax = T2max;
     }
-    launch_conv_to_mono(prev, prev_bs, T, s.last_kernel * c, c, hd_.dec_final_w, hd_.dec_final_b, audio_dev, audio_bs, B, stream_);
+    launch_conv_to_mono(prev, prev_bs, T, s.last_kernel * c, c, hd_.dec_final_w, hd_.dec_final_b, audio_dev, audio_bs, B, st);
     // carry the streaming histories and positions to the next chunk
-    launch_shift_history(b.qbuf.f(), static_cast<long long>(1 + kDecChunk) * M, n, 1, M, B, stream_);
-    launch_shift_history(b.ybuf.f(), ybs, T0, H0, M, B, stream_);
+    launch_shift_history(b.qbuf.f(), static_cast<long long>(1 + kDecChunk) * M, n, 1, M, B, st);
+    launch_shift_history(b.ybuf.f(), ybs, T0, H0, M, B, st);
     c = 8 * s.n_filters;
-    launch_shift_history(b.e0buf.f(), static_cast<long long>(1 + T0max) * c, T0, 1, c, B, stream_);
+    launch_shift_history(b.e0buf.f(), static_cast<long long>(1 + T0max) * c, T0, 1, c, B, st);
     T = T0; Tmax = T0max;
     for (int i = 0; i < 3; ++i) {
         const int co = c / 2, rk = s.res_kernel, hn = i < 2 ? 1 : s.last_kernel - 1;
         T *= s.ratios[i]; Tmax *= s.ratios[i];
-        launch_shift_history(b.uebuf[i].f(), static_cast<long long>(rk - 1 + Tmax) * co, T, rk - 1, co, B, stream_);
-        launch_shift_history(b.ebuf[i].f(), static_cast<long long>(hn + Tmax) * co, T, hn, co, B, stream_);
+        launch_shift_history(b.uebuf[i].f(), static_cast<long long>(rk - 1 + Tmax) * co, T, rk - 1, co, B, st);
+        launch_shift_history(b.ebuf[i].f(), static_cast<long long>(hn + Tmax) * co, T, hn, co, B, st);
         c = co;
     }
-    launch_advance_pos(b.dec_pos.as<int>(), B, T0, stream_);
+    launch_advance_pos(b.dec_pos.as<int>(), B, T0, st);
     b.dec_pos_host += T0;
-    phase_end(2);
+    phase_end(2, st);
 }
 
 }  // namespace ptts

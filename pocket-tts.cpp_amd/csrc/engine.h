@@ -156,16 +156,16 @@ private:
     void transformer(const std::vector<TfLayer>& layers, float* kc, float* vc, long long layer_stride, int cap,
                      const int* pos_dev, int slot0, int nb, int rpb, float* X, int d, int heads, int ffn, float eps,
                      int window, const float* cos_tab, const float* sin_tab, int tab_len, const TfScratch& scratch,
-                     float* last_out, long long last_bs, int last_ld);
+                     float* last_out, long long last_bs, int last_ld, hipStream_t st);
     void lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* adv_dev = nullptr, const int* adv_host = nullptr);
     void lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev);
     void flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B);
-    void mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs);
+    void mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs, hipStream_t st);
     void prefill_utterance(Batch& b, int slot, const Utterance& u);
     void fill_noise(std::vector<std::mt19937>& rngs, const std::vector<Utterance>& utts, int step, float* host_x0);
     Batch* acquire_batch(int B);
-    void phase_begin(int which);
-    void phase_end(int which);
+    void phase_begin(int which, hipStream_t st = nullptr);
+    void phase_end(int which, hipStream_t st = nullptr);
 
     // Device pointers resolved once at construction (name lookups stay off the per-frame path).
     struct Handles {
@@ -180,6 +180,8 @@ private:
     EngineOptions opt_;
     std::unique_ptr<Model> model_;
     hipStream_t stream_ = nullptr;
+    hipStream_t dec_stream_ = nullptr;          // the Mimi decoder runs here, beside the frame loop
+    hipEvent_t latents_ready_ = nullptr, dec_done_ = nullptr;
     std::mutex mu_;
     std::recursive_mutex call_mu_;
     std::mt19937 rng_;
@@ -219,6 +221,8 @@ public:
     // LM I/O
     DevBuf seq_in, cond, eos, x0, xcur, latents, ids;
     TfScratch scratch() const { return TfScratch{h.f(), qkv.f(), q.f(), att.f(), ff.f()}; }
+    DevBuf dx, dh, dqkv, dq, datt, dff;  // decoder-transformer scratch (separate: the decoder overlaps the frame loop)
+    TfScratch dec_scratch() const { return TfScratch{dh.f(), dqkv.f(), dq.f(), datt.f(), dff.f()}; }
     // flow scratch
     DevBuf cemb, ymod, mods;
     DevBuf partial;   // split-K slabs of the decode step [splits][B][d_model] f32

@@ -156,7 +156,7 @@ void Engine::run_staged(Batch& b, std::vector<int>& frames, std::vector<std::vec
     if (eos_log) eos_log->assign(B, std::vector<float>());
     std::vector<int> eos_step(B, -1);
     std::vector<char> done(B, 0);
-    int n_done = 0;
+    int n_done = 0, decoded = 0;
     for (int step = 0; step < opt_.max_frames; ++step) {
         lm_step_dev(b, b.xcur.f(), b.cond.f(), b.eos.f());                                  // :591
         PTTS_HIP(hipMemcpyAsync(b.h_eos, b.eos.p, static_cast<size_t>(B) * 4, hipMemcpyDeviceToHost, stream_));
@@ -176,16 +176,30 @@ void Engine::run_staged(Batch& b, std::vector<int>& frames, std::vector<std::vec
                                   static_cast<size_t>(L) * 4, static_cast<size_t>(L) * 4, B, hipMemcpyDeviceToDevice, stream_));
         for (int i = 0; i < B; ++i)
             if (!done[i]) frames[i]++;
+        // Every full 15-frame chunk goes to the decoder stream as soon as its latents exist: the decoder
+        // never feeds back into the frame loop, so it runs beside the following frames (the reference decodes
+        // after the loop, :640; the chunk boundaries and the carried state are the same).
+        if ((step + 1) % kDecChunk == 0) {
+            PTTS_HIP(hipEventRecord(latents_ready_, stream_));
+            PTTS_HIP(hipStreamWaitEvent(dec_stream_, latents_ready_, 0));
+            const int f0 = step + 1 - kDecChunk;
+            mimi_decode_dev(b, b.latents.f() + static_cast<size_t>(f0) * L, static_cast<long long>(opt_.max_frames) * L, kDecChunk,
+                            b.audio_all.f() + static_cast<size_t>(f0) * fs, static_cast<long long>(opt_.max_frames) * fs, dec_stream_);
+            decoded = step + 1;
+        }
     }
     int fmax = 0;
     for (int i = 0; i < B; ++i) fmax = std::max(fmax, frames[i]);
-    // decode in chunks of <= 15 frames with one carried state per utterance (:454-546, :640)
-    for (int f0 = 0; f0 < fmax; f0 += kDecChunk) {
+    // remaining frames (:454-546): chunks of <= 15 with the same carried state
+    PTTS_HIP(hipEventRecord(latents_ready_, stream_));
+    PTTS_HIP(hipStreamWaitEvent(dec_stream_, latents_ready_, 0));
+    for (int f0 = decoded; f0 < fmax; f0 += kDecChunk) {
         const int n = std::min(kDecChunk, fmax - f0);
         mimi_decode_dev(b, b.latents.f() + static_cast<size_t>(f0) * L, static_cast<long long>(opt_.max_frames) * L, n,
-                        b.audio_all.f() + static_cast<size_t>(f0) * fs, static_cast<long long>(opt_.max_frames) * fs);
+                        b.audio_all.f() + static_cast<size_t>(f0) * fs, static_cast<long long>(opt_.max_frames) * fs, dec_stream_);
     }
     PTTS_HIP(hipStreamSynchronize(stream_));
+    PTTS_HIP(hipStreamSynchronize(dec_stream_));
 }
 
 void Engine::fetch_staged(Batch& b, const std::vector<int>& frames, std::vector<UtteranceResult>& out, bool want_latents) {
@@ -249,7 +263,7 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
         for (int f0 = 0; f0 < count; f0 += kDecChunk) {  // sub-chunks of <= 15 frames (:796)
             const int n = std::min(kDecChunk, count - f0);
             mimi_decode_dev(b, b.latents.f() + static_cast<size_t>(first + f0) * L, static_cast<long long>(opt_.max_frames) * L, n,
-                            b.audio.f(), static_cast<long long>(kDecChunk) * fs);
+                            b.audio.f(), static_cast<long long>(kDecChunk) * fs, stream_);
             PTTS_HIP(hipMemcpyAsync(chunk_audio.data() + static_cast<size_t>(f0) * fs, b.audio.p, static_cast<size_t>(n) * fs * 4,
                                     hipMemcpyDeviceToHost, stream_));
             PTTS_HIP(hipStreamSynchronize(stream_));
@@ -361,7 +375,7 @@ std::vector<float> Engine::encode_voice(const float* audio, int S) {
     if (T > model_->mimi_tab_len) throw std::runtime_error("voice clip exceeds the rotary table");
     transformer(hd_.enc, kc.f(), vc.f(), static_cast<long long>(T) * M, T, pos.as<int>(), 0, 1, T, y.f(), M, s.mimi_heads, s.mimi_ffn,
                 s.mimi_eps, s.mimi_context, model_->mimi_cos, model_->mimi_sin, model_->mimi_tab_len, sc,
-                yd.f() + static_cast<size_t>(U) * M, 0, M);
+                yd.f() + static_cast<size_t>(U) * M, 0, M, stream_);
     DevBuf d(static_cast<size_t>(Nv) * M * 4), o(static_cast<size_t>(Nv) * D * 4);
     GemmArgs ds;
     ds.A = yd.f(); ds.lda = U * M; ds.W = hd_.enc_ds.p; ds.wtype = hd_.enc_ds.wtype; ds.M = Nv; ds.N = M; ds.K = 2 * U * M; ds.C = d.f(); ds.ldc = M;
@@ -429,7 +443,7 @@ void Engine::op_mimi_decode(Batch* b, const float* latents, int n, float* audio)
     // stage the chunk at the front of each utterance's latent buffer
     PTTS_HIP(hipMemcpy2DAsync(b->latents.p, static_cast<size_t>(opt_.max_frames) * L * 4, latents, static_cast<size_t>(n) * L * 4,
                               static_cast<size_t>(n) * L * 4, b->B, hipMemcpyHostToDevice, stream_));
-    mimi_decode_dev(*b, b->latents.f(), static_cast<long long>(opt_.max_frames) * L, n, b->audio.f(), static_cast<long long>(kDecChunk) * fs);
+    mimi_decode_dev(*b, b->latents.f(), static_cast<long long>(opt_.max_frames) * L, n, b->audio.f(), static_cast<long long>(kDecChunk) * fs, stream_);
     PTTS_HIP(hipMemcpy2DAsync(audio, static_cast<size_t>(n) * fs * 4, b->audio.p, static_cast<size_t>(kDecChunk) * fs * 4,
                               static_cast<size_t>(n) * fs * 4, b->B, hipMemcpyDeviceToHost, stream_));
     PTTS_HIP(hipStreamSynchronize(stream_));
