@@ -125,8 +125,9 @@ POCKET_TTS_API int ptts_audio_save_wav(const char* path, const float* samples, i
 POCKET_TTS_API int ptts_audio_resample(const float* in, int n, int in_rate, int out_rate, float* out, int cap);
 POCKET_TTS_API int ptts_audio_normalize(const float* in, int n, float* out);
 
-/* Benchmark support: HIP-event timing of the three per-frame phases on the engine's stream.
- * times_ms[0..2] = LM step, flow head, decoder chunk totals; calls[0..2] = launches of each. */
+/* Benchmark support: HIP-event timing on the streams the engine launches on.  Both arrays hold 4 entries:
+ * [0] LM frame step (kernel chain), [1] flow phase (adaLN GEMMs + fused head), [2] decoder chunk,
+ * [3] the fused flow-head kernel alone; times_ms = totals, calls = number of launches of each. */
 POCKET_TTS_API int ptts_phase_timing(PocketTTSHandle handle, int enable);
 POCKET_TTS_API int ptts_phase_times(PocketTTSHandle handle, double* times_ms, long* calls);
 /* bytes[0..3] = GEMM weight bytes (compute precision) of the LM, the flow head, the decoder, the encoder */

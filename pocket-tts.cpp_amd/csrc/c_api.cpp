@@ -482,8 +482,8 @@ POCKET_TTS_API int ptts_phase_times(PocketTTSHandle handle, double* times_ms, lo
     if (!handle || !times_ms || !calls) { set_error("Invalid parameters"); return -1; }
     return guarded("phase_times: ", [&] {
         auto t = tts_of(handle)->engine().phase_times();
-        times_ms[0] = t.lm_ms; times_ms[1] = t.flow_ms; times_ms[2] = t.dec_ms;
-        calls[0] = t.lm_calls; calls[1] = t.flow_calls; calls[2] = t.dec_calls;
+        times_ms[0] = t.lm_ms; times_ms[1] = t.flow_ms; times_ms[2] = t.dec_ms; times_ms[3] = t.head_ms;
+        calls[0] = t.lm_calls; calls[1] = t.flow_calls; calls[2] = t.dec_calls; calls[3] = t.head_calls;
         return 0;
     });
 }

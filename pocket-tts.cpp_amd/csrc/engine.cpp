@@ -494,7 +494,8 @@ Engine::PhaseTimes Engine::phase_times() {
         if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) {
             if (pe.first == 0) { times_.lm_ms += ms; times_.lm_calls++; }
             else if (pe.first == 1) { times_.flow_ms += ms; times_.flow_calls++; }
-            else { times_.dec_ms += ms; times_.dec_calls++; }
+            else if (pe.first == 2) { times_.dec_ms += ms; times_.dec_calls++; }
+            else { times_.head_ms += ms; times_.head_calls++; }
         }
         (void)hipEventDestroy(pe.second.first);
         (void)hipEventDestroy(pe.second.second);
@@ -676,7 +677,9 @@ void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long
     fa.w_in = model_->flow_in_packed; fa.b_in = hd_.flow_in_b; fa.w_out = model_->flow_out_packed; fa.b_out = hd_.flow_out_b;
     fa.w_fc1 = model_->d_w_fc1; fa.w_fc2 = model_->d_w_fc2; fa.b_fc1 = model_->d_b_fc1; fa.b_fc2 = model_->d_b_fc2;
     fa.ln_g = model_->d_ln_g; fa.ln_b = model_->d_ln_b; fa.wtype = model_->flow_wtype; fa.eps = s.flow_eps;
+    phase_begin(3);
     launch_flow_head(fa, stream_);
+    phase_end(3);
     phase_end(1);
 }
 

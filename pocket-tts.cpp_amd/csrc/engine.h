@@ -145,7 +145,7 @@ public:
     void op_mimi_decode(Batch* b, const float* latents /*[B][n][latent]*/, int n, float* audio /*[B][n*frame]*/);
 
     // timing hooks for the benchmark: HIP events recorded on the engine stream around named phases
-    struct PhaseTimes { double lm_ms = 0, flow_ms = 0, dec_ms = 0; long lm_calls = 0, flow_calls = 0, dec_calls = 0; };
+    struct PhaseTimes { double lm_ms = 0, flow_ms = 0, dec_ms = 0, head_ms = 0; long lm_calls = 0, flow_calls = 0, dec_calls = 0, head_calls = 0; };
     void enable_phase_timing(bool on);
     PhaseTimes phase_times();
 

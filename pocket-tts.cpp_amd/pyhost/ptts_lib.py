@@ -411,10 +411,10 @@ class Engine:
         _check(self.L.ptts_phase_timing(self.h, 1 if on else 0), "phase_timing")
 
     def phase_times(self):
-        t = (C.c_double * 3)()
-        c = (C.c_long * 3)()
+        t = (C.c_double * 4)()
+        c = (C.c_long * 4)()
         _check(self.L.ptts_phase_times(self.h, t, c), "phase_times")
-        return dict(lm_ms=t[0], flow_ms=t[1], dec_ms=t[2], lm_calls=c[0], flow_calls=c[1], dec_calls=c[2])
+        return dict(lm_ms=t[0], flow_ms=t[1], dec_ms=t[2], head_ms=t[3], lm_calls=c[0], flow_calls=c[1], dec_calls=c[2], head_calls=c[3])
 
     def weight_bytes(self):
         b = (C.c_ulonglong * 4)()

@@ -281,6 +281,22 @@ def make_pack(path: str, spec: Spec, seed: int = 1234, eos_bias: float = -20.0,
     return w
 
 
+F32_ONLY_WEIGHTS = ("dec.up.w", "dec.final.w", "enc.conv0.w", "lm.eos.w")
+
+
+def bf16_round(a: np.ndarray) -> np.ndarray:
+    """float32 -> nearest-even bfloat16 -> float32 (the rounding the engine applies to its bf16 weight copy)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+def bf16_model(weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """The model the bf16 engine actually holds: matrix weights rounded to bf16, everything else
+    (biases, norms, embedding table, depthwise/1-channel convs, EOS head) left in float32."""
+    return {k: (bf16_round(v) if k.endswith(".w") and k not in F32_ONLY_WEIGHTS else v) for k, v in weights.items()}
+
+
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser(description="write a seeded synthetic Pocket TTS weight pack")

@@ -1,0 +1,155 @@
+"""CPU-only tests of the checker itself and of the multi-rank host logic.
+
+The C oracle is compared with (1) the committed vectors in tests/golden/tiny_network.npz, (2) an
+independent float64 torch transcription of the same five graphs (tests/torch_ref.py) that evaluates whole
+sequences at once, so agreement also proves the oracle's streaming state (KV cache, conv history, ring
+buffer) is equivalent to the stateless computation.  The network arithmetic itself has no reference output
+to pin against (the ONNX graphs and their runtime are not in the reference tree): parity unpinned.
+"""
+import os
+import subprocess
+import sys
+import textwrap
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def tiny(packs, oracle_mod):
+    path, spec, w = packs["tiny"]
+    return oracle_mod.Oracle(path), spec, w
+
+
+def test_oracle_reproduces_golden_vectors(tiny):
+    o, spec, w = tiny
+    g = np.load(os.path.join(GOLD, "tiny_network.npz"))
+    assert zlib.crc32(b"".join(w[k].tobytes() for k in sorted(w))) == int(g["pack_crc32"][0])
+    np.testing.assert_allclose(o.text_conditioner(g["ids"]), g["text_emb"], rtol=0, atol=0)
+    np.testing.assert_allclose(o.flow_euler(g["cond"], g["x0"], 10), g["flow10"], rtol=0, atol=2e-6)
+    r = o.generate(g["ids"], g["voice"], lsd_steps=10, max_frames=8)
+    assert r["frames"] == len(g["latents"]) == 8
+    # different OpenMP reduction order only; the 8-frame AR loop amplifies 1e-7 to ~1e-5
+    np.testing.assert_allclose(r["latents"], g["latents"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(r["eos"], g["eos"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(r["audio"][: len(g["audio"])], g["audio"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(o.mimi_encode(g["clip"]), g["enc"], rtol=0, atol=1e-5)
+
+
+def test_oracle_matches_float64_transcription(tiny):
+    import torch
+    from torch_ref import TorchRef
+    o, spec, w = tiny
+    t = TorchRef(spec, w)
+    rng = np.random.default_rng(3)
+    ids = rng.integers(0, spec.vocab, 7).astype(np.int64)
+    voice = (rng.standard_normal((4, spec.d_model)) * 0.5).astype(np.float32)
+    text = o.text_conditioner(ids)
+    np.testing.assert_array_equal(text, t.text_conditioner(ids).numpy().astype(np.float32))
+    # flow_lm_main: prefill in two calls + 5 single-row steps  ==  one whole-sequence pass
+    seq = (rng.standard_normal((5, spec.latent_dim)) * 0.7).astype(np.float32)
+    seq[0] = np.nan
+    st = o.lm_state(64)
+    o.lm_main(st, None, voice)
+    o.lm_main(st, None, text)
+    cond, eos = zip(*[o.lm_main(st, seq[i:i + 1], None) for i in range(len(seq))])
+    tc, te = t.lm_full(voice, text, seq)
+    assert np.abs(np.array(cond).reshape(5, -1) - tc.numpy()).max() < 2e-5
+    assert np.abs(np.array(eos).ravel() - te.numpy()).max() < 2e-5
+    # flow head
+    c = rng.standard_normal(spec.d_model).astype(np.float32)
+    x0 = rng.standard_normal(spec.latent_dim).astype(np.float32)
+    assert np.abs(o.flow(c, 0.3, 0.4, x0) - t.flow(c, 0.3, 0.4, x0).numpy()).max() < 2e-5
+    assert np.abs(o.flow_euler(c, x0, 10) - t.flow_euler(c, x0, 10).numpy()).max() < 2e-5
+    # decoder: chunks of 3 + 1 + 4 frames with carried state  ==  one stateless pass
+    lat = (rng.standard_normal((8, spec.latent_dim)) * 0.8).astype(np.float32)
+    ds = o.dec_state()
+    audio = np.concatenate([o.mimi_decode(ds, lat[a:b]) for a, b in ((0, 3), (3, 4), (4, 8))])
+    ta = t.mimi_decode_full(lat).numpy()
+    assert audio.shape == ta.shape == (8 * spec.frame_size,)
+    assert np.abs(audio - ta).max() < 5e-5 * max(1.0, np.abs(ta).max())
+    # encoder
+    clip = (rng.standard_normal(5 * spec.frame_size + 7) * 0.3).astype(np.float32)
+    enc = o.mimi_encode(clip)
+    tenc = t.mimi_encode(clip).numpy()
+    assert enc.shape == tenc.shape
+    assert np.abs(enc - tenc).max() < 5e-5 * max(1.0, np.abs(tenc).max())
+
+
+def test_oracle_stop_rule_and_chunking(packs, oracle_mod):
+    """EOS threshold -4.0, three frames after the first EOS, the EOS step's own frame is kept
+    (src/pocket_tts.cpp:596-603); decoding in 15-frame chunks equals decoding in 4-frame chunks."""
+    path, spec, _ = packs["tiny_eos"]
+    o = oracle_mod.Oracle(path)
+    rng = np.random.default_rng(0)
+    hit = False
+    for trial in range(6):
+        ids = rng.integers(0, spec.vocab, 6).astype(np.int64)
+        voice = (rng.standard_normal((3, spec.d_model)) * 0.5).astype(np.float32)
+        r = o.generate(ids, voice, lsd_steps=4, max_frames=40)
+        eos = r["eos"]
+        first = np.flatnonzero(eos > -4.0)
+        if len(first) and first[0] + 3 < 40:
+            hit = True
+            assert r["frames"] == first[0] + 3 and len(eos) == first[0] + 4
+        else:
+            assert r["frames"] == 40
+        assert len(r["audio"]) == r["frames"] * spec.frame_size
+        r2 = o.generate(ids, voice, lsd_steps=4, max_frames=40, chunk_frames=4)
+        assert r2["frames"] == r["frames"]
+        assert np.abs(r2["audio"] - r["audio"]).max() < 1e-5
+    assert hit, "no trial crossed the EOS threshold: the tiny_eos pack no longer exercises the stop rule"
+
+
+# ----------------------------------------------------------------------------- multi-rank host logic
+
+def test_partition_is_balanced_and_deterministic():
+    import ptts_shard
+    costs = [125, 40, 300, 300, 10, 77, 125, 125, 500, 3]
+    for world in (1, 2, 3, 8):
+        parts = ptts_shard.partition(costs, world)
+        assert sorted(sum(parts, [])) == list(range(len(costs)))
+        loads = [sum(costs[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(costs)
+        assert parts == ptts_shard.partition(list(costs), world)
+    assert ptts_shard.partition([], 2) == [[], []]
+    b = ptts_shard.batches([0, 1, 2, 3, 4], costs, 2)
+    assert b == [[2, 3], [0, 1], [4]]
+    with pytest.raises(ValueError):
+        ptts_shard.partition(costs, 0)
+
+
+def test_two_rank_job_reduction_over_gloo(tmp_path):
+    """world_size 2 on CPU: both ranks derive the same partition, the reported wall time is the slower
+    rank's and the units are summed - the contract bench.py's aggregate line relies on."""
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent(f"""
+        import json, os, sys, time
+        sys.path.insert(0, {os.path.join(ROOT, 'pocket-tts.cpp_amd', 'pyhost')!r})
+        import torch, torch.distributed as dist
+        import ptts_shard
+        rank, local_rank, world = ptts_shard.env_ranks()
+        dist.init_process_group("gloo")
+        costs = [125, 40, 300, 300, 10, 77, 125]
+        mine = ptts_shard.partition(costs, world)[rank]
+        ptts_shard.barrier(dist, torch.device("cpu"))
+        t0 = time.perf_counter()
+        time.sleep(0.05 * (rank + 1))
+        ptts_shard.barrier(dist, torch.device("cpu"))
+        dt = 0.1 * (rank + 1)
+        dt_max, units = ptts_shard.reduce_job(dt, sum(costs[i] for i in mine), dist, torch.device("cpu"))
+        json.dump(dict(rank=rank, mine=mine, dt_max=dt_max, units=units), open({str(tmp_path)!r} + f"/out{{rank}}.json", "w"))
+        dist.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29541", str(script)], check=True, env=env, timeout=240, capture_output=True)
+    import json
+    r0, r1 = (json.load(open(tmp_path / f"out{r}.json")) for r in (0, 1))
+    assert sorted(r0["mine"] + r1["mine"]) == list(range(7)) and not set(r0["mine"]) & set(r1["mine"])
+    assert r0["dt_max"] == r1["dt_max"] == pytest.approx(0.2)
+    assert r0["units"] == r1["units"] == 977.0

@@ -1,0 +1,109 @@
+"""GPU parity at the full model size (d_model 1024, 6 layers, flow 512x6, Mimi 512, 1920 samples/frame),
+seeded synthetic weights, through the C ABI.  fp32: per-frame latents max-abs <= 1e-3 and PCM SNR >= 40 dB
+against the oracle.  bf16: per-frame latents max-abs <= 2e-2.  Also the committed golden fixture, which needs
+no oracle at run time."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import oracle_decode, oracle_replay, snr_db
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F = 5
+
+
+@pytest.fixture(scope="module")
+def full(tmp_path_factory, oracle_mod):
+    import ptts_lib
+    import ptts_pack as pp
+    ptts_lib.load()
+    d = tmp_path_factory.mktemp("full")
+    spec = pp.Spec.full()
+    path = str(d / "full.ptts")
+    w = pp.make_pack(path, spec, seed=1234, eos_bias=-20.0)
+    path_q = str(d / "full_bf16w.ptts")
+    pp.write_pack(path_q, spec, pp.bf16_model(w))
+    rng = np.random.default_rng(77)
+    ids = [rng.integers(0, spec.vocab, t).astype(np.int64) for t in (32, 11, 20)]
+    voices = [(rng.standard_normal((v, spec.d_model)) * 0.5).astype(np.float32) for v in (62, 30, 45)]
+    return dict(lib=ptts_lib, spec=spec, path=path, path_q=path_q, ids=ids, voices=voices,
+                o=oracle_mod.Oracle(path), oq=oracle_mod.Oracle(path_q))
+
+
+def _note(line):
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/fullsize_parity.txt", "a") as f:
+            f.write(line + "\n")
+
+
+def test_full_fp32_offline_parity(full):
+    eng = full["lib"].Engine(full["path"], precision="fp32", temperature=0.0, lsd_steps=10, max_frames=F)
+    res = eng.generate_ids(full["ids"], full["voices"])
+    worst, worst_snr = 0.0, 1e9
+    for i in range(3):
+        lat, eos, frames = oracle_replay(full["o"], full["ids"][i], full["voices"][i], res[i]["latents"], 10, F)
+        assert res[i]["frames"] == frames == F
+        assert res[i]["audio"].shape[0] == F * 1920
+        worst = max(worst, float(np.abs(res[i]["latents"] - lat).max()), float(np.abs(res[i]["eos"] - eos).max()))
+        worst_snr = min(worst_snr, snr_db(oracle_decode(full["o"], res[i]["latents"]), res[i]["audio"]))
+    _note(f"fp32 full size: per-frame latent/eos max-abs {worst:.3e}, PCM SNR {worst_snr:.1f} dB")
+    assert worst <= 1e-3 and worst_snr >= 40.0
+    eng.close()
+
+
+def test_full_bf16_offline_parity(full):
+    """Per-frame (same history on both sides) latent error of the bf16 engine.  The engine's model IS the
+    bf16-rounded weight set, so the 2e-2 bound is taken against the oracle evaluating that same model in
+    float32; the distance to the oracle on the unrounded weights (weight quantisation included) is recorded
+    and bounded at 5e-2."""
+    eng = full["lib"].Engine(full["path"], precision="bf16", temperature=0.0, lsd_steps=10, max_frames=F)
+    res = eng.generate_ids(full["ids"], full["voices"])
+    worst_q = worst_f = 0.0
+    snr_q = 1e9
+    for i in range(3):
+        latq, _, frames = oracle_replay(full["oq"], full["ids"][i], full["voices"][i], res[i]["latents"], 10, F)
+        latf, _, _ = oracle_replay(full["o"], full["ids"][i], full["voices"][i], res[i]["latents"], 10, F)
+        assert res[i]["frames"] == frames == F
+        worst_q = max(worst_q, float(np.abs(res[i]["latents"] - latq).max()))
+        worst_f = max(worst_f, float(np.abs(res[i]["latents"] - latf).max()))
+        snr_q = min(snr_q, snr_db(oracle_decode(full["oq"], res[i]["latents"]), res[i]["audio"]))
+    _note(f"bf16 full size: per-frame latent max-abs vs oracle on bf16-rounded weights {worst_q:.3e}, "
+          f"vs oracle on f32 weights {worst_f:.3e}, PCM SNR vs oracle(bf16 weights) {snr_q:.1f} dB")
+    assert worst_q <= 2e-2, worst_q
+    assert worst_f <= 5e-2, worst_f
+    assert snr_q >= 30.0
+    eng.close()
+
+
+def test_full_streaming_first_chunk(full):
+    eng = full["lib"].Engine(full["path"], precision="fp32", temperature=0.0, lsd_steps=10, max_frames=10)
+    total, chunks, t_first = eng.streaming_ids(full["ids"][0], full["voices"][0], chunk_frames=5)
+    assert total == 10 * 1920 and [len(c) for c, _ in chunks] == [5 * 1920, 5 * 1920]
+    assert [f for _, f in chunks] == [0, 0]     # a stream that ends on a chunk boundary never reports is_final
+    off = eng.generate_ids(full["ids"][:1], full["voices"][:1])[0]
+    np.testing.assert_array_equal(np.concatenate([c for c, _ in chunks]), off["audio"])
+    _note(f"fp32 full size streaming: first 5-frame chunk after {t_first * 1e3:.1f} ms")
+    eng.close()
+
+
+def test_tiny_golden_fixture(packs):
+    """Committed vectors (tests/golden/tiny_network.npz, made by tests/golden/make_golden.py): no oracle call here."""
+    import zlib
+    import ptts_lib
+    path, spec, w = packs["tiny"]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "tiny_network.npz"))
+    assert zlib.crc32(b"".join(w[k].tobytes() for k in sorted(w))) == int(g["pack_crc32"][0])
+    eng = ptts_lib.Engine(path, precision="fp32", temperature=0.0, lsd_steps=10, max_frames=8)
+    np.testing.assert_array_equal(eng.text_conditioner(g["ids"]), g["text_emb"])
+    assert np.abs(eng.flow_euler(g["cond"][None], g["x0"][None])[0] - g["flow10"]).max() < 1e-4
+    r = eng.generate_ids([g["ids"]], [g["voice"]])[0]
+    assert r["frames"] == 8
+    assert np.abs(r["latents"][:3] - g["latents"][:3]).max() < 1e-3      # free-running: early frames only
+    assert np.abs(r["eos"][:3] - g["eos"][:3]).max() < 1e-3
+    assert snr_db(g["audio"][: spec.frame_size], r["audio"][: spec.frame_size]) >= 40.0
+    enc = eng.mimi_encode(g["clip"])
+    assert enc.shape == g["enc"].shape and np.abs(enc - g["enc"]).max() < 1e-3
+    eng.close()
