@@ -5,14 +5,17 @@
 //  skinny_gemm   M x N x K with M tiled by 64: a workgroup of 4 waves owns 64 output columns and a K-slice;
 //                wave w owns column tile w for all row tiles.  Weights are fragment-major (one wave-level
 //                load = 1 KiB contiguous = one MFMA B operand per lane) and go L2 -> VGPR one K-chunk ahead
-//                of use; activations (already in the compute type) go through a double-buffered LDS tile
-//                shared by the 4 waves.  Long K is split over workgroups into f32 partial slabs.
+//                of use; activations (always f32 in memory) go through a double-buffered LDS tile shared
+//                by the 4 waves.  Long K is split over workgroups into f32 partial slabs.
 //  add_norm      the consumer of those slabs: per row, sums the K-slices in a fixed order (bitwise
 //                reproducible), applies layer scale and the residual, then LayerNorms the updated row for
 //                the next matrix product (and, for the last layer, emits conditioning + EOS logit).
 //  attn_decode   RoPE, KV-cache append and single-query attention for one (row, head) per wave.
 //
 // f32 weights use v_mfma_f32_16x16x4_f32 (exact f32 FMA chain), bf16 weights v_mfma_f32_16x16x32_bf16.
+// With bf16 weights an f32 activation a is staged as two bf16 terms, hi = bf16(a) and lo = bf16(a - hi),
+// and each weight fragment is multiplied with both: the product then carries the activation to ~16
+// mantissa bits, so the only rounding left relative to f32 arithmetic is the weights' own bf16 storage.
 #include <hip/hip_runtime.h>
 
 #include <stdexcept>
@@ -26,7 +29,16 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 template <typename CT> struct SkinnyTraits { static constexpr int kstep = 16, per = 4, kch = 128, pad = 4; };
-template <> struct SkinnyTraits<__bf16> { static constexpr int kstep = 32, per = 8, kch = 256, pad = 8; };
+template <> struct SkinnyTraits<__bf16> { static constexpr int kstep = 32, per = 8, kch = 128, pad = 8; };
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+// a -> (hi, lo) with hi + lo == a to ~16 mantissa bits
+__device__ __forceinline__ void split_bf16(const float4 v, bf16x4& hi, bf16x4& lo) {
+    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
 
 __device__ __forceinline__ float act_dev(float v, int act) {
     switch (act) {
@@ -40,11 +52,13 @@ __device__ __forceinline__ float act_dev(float v, int act) {
 template <typename CT>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     using T = SkinnyTraits<CT>;
-    constexpr int KSTEP = T::kstep, PER = T::per, KCH = T::kch, LDA = KCH + T::pad;
-    constexpr int NKS = KCH / KSTEP;                   // k-steps per chunk (8)
-    constexpr int PIECES = KCH * (int)sizeof(CT) / 16;  // 16-byte pieces per row of a chunk (32)
-    constexpr int APT = 64 * PIECES / 256;              // A pieces per thread per chunk (8)
-    __shared__ __attribute__((aligned(16))) CT As[2][64 * LDA];
+    constexpr bool kBf16 = !std::is_same<CT, float>::value;
+    constexpr int KSTEP = T::kstep, KCH = T::kch, LDA = KCH + T::pad;
+    constexpr int NKS = KCH / KSTEP;        // k-steps per chunk
+    constexpr int PIECES = KCH / 4;         // float4 pieces per row of a chunk (32)
+    constexpr int APT = 64 * PIECES / 256;  // A pieces per thread per chunk (8)
+    constexpr int PLANES = kBf16 ? 2 : 1;   // bf16: hi and lo planes
+    __shared__ __attribute__((aligned(16))) CT As[2][PLANES][64 * LDA];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x * 4 + wave;
@@ -56,15 +70,16 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     const int KS_total = a.K / KSTEP;
     const uint4* wbase = (const uint4*)a.Wp + (long long)nt * KS_total * 64 + lane;
 
-    uint4 areg[APT], bnext[NKS], bcur[NKS];
+    float4 areg[APT];
+    uint4 bnext[NKS], bcur[NKS];
     auto load_chunk = [&](int c) {
         const int kc0 = c * KCH;  // offset inside the slice
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int id = tid + 256 * i, row = id / PIECES, piece = id % PIECES;
-            const int k = kc0 + piece * (16 / (int)sizeof(CT));
+            const int k = kc0 + piece * 4;
             const bool ok = (m0 + row) < a.M && k < Kc;
-            areg[i] = ok ? *(const uint4*)((const CT*)a.A + (long long)(m0 + row) * a.lda + k_begin + k) : make_uint4(0u, 0u, 0u, 0u);
+            areg[i] = ok ? *(const float4*)(a.A + (long long)(m0 + row) * a.lda + k_begin + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < NKS; ++i) {
@@ -80,11 +95,19 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
 
     load_chunk(0);
     for (int c = 0; c < nchunks; ++c) {
-        CT* buf = As[c & 1];
+        CT* buf = As[c & 1][0];
+        CT* buf_lo = As[c & 1][PLANES - 1];
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int id = tid + 256 * i, row = id / PIECES, piece = id % PIECES;
-            *(uint4*)((char*)buf + ((long long)row * LDA * sizeof(CT)) + piece * 16) = areg[i];
+            if constexpr (kBf16) {
+                bf16x4 hi, lo;
+                split_bf16(areg[i], hi, lo);
+                *(bf16x4*)(buf + row * LDA + piece * 4) = hi;
+                *(bf16x4*)(buf_lo + row * LDA + piece * 4) = lo;
+            } else {
+                *(float4*)(buf + row * LDA + piece * 4) = areg[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < NKS; ++i) bcur[i] = bnext[i];
@@ -92,7 +115,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
         if (c + 1 < nchunks) load_chunk(c + 1);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            if constexpr (std::is_same<CT, float>::value) {
+            if constexpr (!kBf16) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const float4 a4 = *(const float4*)(buf + (mt * 16 + r) * LDA + ks * 16 + 4 * g);
@@ -105,8 +128,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
                 const bf16x8 b8 = __builtin_bit_cast(bf16x8, bcur[ks]);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const bf16x8 a8 = *(const bf16x8*)(buf + (mt * 16 + r) * LDA + ks * 32 + 8 * g);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[mt], 0, 0, 0);
+                    const bf16x8 lo8 = *(const bf16x8*)(buf_lo + (mt * 16 + r) * LDA + ks * 32 + 8 * g);
+                    const bf16x8 hi8 = *(const bf16x8*)(buf + (mt * 16 + r) * LDA + ks * 32 + 8 * g);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo8, b8, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi8, b8, acc[mt], 0, 0, 0);
                 }
             }
         }
@@ -124,9 +149,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
                 a.P[((long long)blockIdx.y * a.M + row) * a.N + col] = v;
             } else {
                 if (a.bias) v += a.bias[col];
-                v = act_dev(v, a.act);
-                if (a.c_ct) ((CT*)a.C)[(long long)row * a.ldc + col] = (CT)v;
-                else ((float*)a.C)[(long long)row * a.ldc + col] = v;
+                a.C[(long long)row * a.ldc + col] = act_dev(v, a.act);
             }
         }
     }
@@ -135,8 +158,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
 void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return;
     const bool bf = a.wtype == W_BF16;
-    const int kstep = bf ? 32 : 16, ealign = bf ? 8 : 4;
-    if (a.N % 16 || a.K % kstep || a.splits <= 0 || a.K % a.splits || (a.K / a.splits) % kstep || (a.lda % ealign) || ((uintptr_t)a.A & 15))
+    const int kstep = bf ? 32 : 16;
+    if (a.N % 16 || a.K % kstep || a.splits <= 0 || a.K % a.splits || (a.K / a.splits) % kstep || (a.lda % 4) || ((uintptr_t)a.A & 15))
         throw std::runtime_error("skinny gemm: shape not tileable (N % 16, K % k-step, K % splits, lda alignment)");
     if (!a.P && a.splits != 1) throw std::runtime_error("skinny gemm: split K needs a partial buffer");
     dim3 grid((a.N + 63) / 64, a.splits, (a.M + 63) / 64), block(256);
@@ -162,7 +185,6 @@ __device__ __forceinline__ float block_sum4(float v, float* red, int tid) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <typename CT>
 __global__ __launch_bounds__(256) void add_norm_kernel(AddNormArgs a) {
     constexpr int MAXS = 16;
     __shared__ float red[4];
@@ -196,14 +218,7 @@ __global__ __launch_bounds__(256) void add_norm_kernel(AddNormArgs a) {
     if (on) {
         const float4 g4 = *(const float4*)(a.g + c), b4 = *(const float4*)(a.b + c);
         const float y0 = d0 * rstd * g4.x + b4.x, y1 = d1 * rstd * g4.y + b4.y, y2 = d2 * rstd * g4.z + b4.z, y3 = d3 * rstd * g4.w + b4.w;
-        if (a.H) {
-            if (a.h_ct) {
-                CT* dst = (CT*)a.H + (long long)m * a.D + c;
-                dst[0] = (CT)y0; dst[1] = (CT)y1; dst[2] = (CT)y2; dst[3] = (CT)y3;
-            } else {
-                *(float4*)((float*)a.H + (long long)m * a.D + c) = make_float4(y0, y1, y2, y3);
-            }
-        }
+        if (a.H) *(float4*)(a.H + (long long)m * a.D + c) = make_float4(y0, y1, y2, y3);
         if (a.H32) *(float4*)(a.H32 + (long long)m * a.D + c) = make_float4(y0, y1, y2, y3);
         if (a.dot_w) { const float4 w4 = *(const float4*)(a.dot_w + c); dot = (y0 * w4.x + y1 * w4.y) + (y2 * w4.z + y3 * w4.w); }
     }
@@ -218,8 +233,7 @@ void launch_add_norm(const AddNormArgs& a, hipStream_t s) {
     if (a.D % 4 || a.D > 1024 || (a.ldx & 3)) throw std::runtime_error("add_norm: width must be a multiple of 4 and <= 1024");
     if (a.P && (a.splits < 1 || a.splits > 16)) throw std::runtime_error("add_norm: 1..16 K-slices supported");
     dim3 grid(a.M), block(256);
-    if (a.wtype == W_BF16) hipLaunchKernelGGL(add_norm_kernel<__bf16>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(add_norm_kernel<float>, grid, block, 0, s, a);
+    hipLaunchKernelGGL(add_norm_kernel, grid, block, 0, s, a);
 }
 
 // ------------------------------------------------------------------ decode attention, one 4-wave block per (row, head)
@@ -228,7 +242,6 @@ void launch_add_norm(const AddNormArgs& a, hipStream_t s) {
 // softmax over its range (lane per key for the scores, then 4 key groups x 16 channel quads for P.V) and
 // leaves (max, sum, unnormalised output) in LDS; wave 0 merges the four and adds the new token, whose
 // rotated key and value never leave registers.  Every wave rotates q itself; wave 0 appends k, v to the cache.
-template <typename CT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -328,8 +341,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
         acc += comb[i * 68 + 4 + lane] * f;
     }
     const float out = acc / tot;
-    if (a.out_ct) ((CT*)a.out)[(long long)m * a.d + h * 64 + lane] = (CT)out;
-    else ((float*)a.out)[(long long)m * a.d + h * 64 + lane] = out;
+    a.out[(long long)m * a.d + h * 64 + lane] = out;
 }
 
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
@@ -339,8 +351,7 @@ void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     const size_t smem = ((size_t)4 * (64 + scap) + 4 * 68) * sizeof(float);
     if (smem > 64 * 1024) throw std::runtime_error("attention: context capacity too large for the LDS score buffer");
     dim3 grid((unsigned)(a.M * a.heads)), block(256);
-    if (a.wtype == W_BF16) hipLaunchKernelGGL(attn_decode_kernel<__bf16>, grid, block, smem, s, a);
-    else hipLaunchKernelGGL(attn_decode_kernel<float>, grid, block, smem, s, a);
+    hipLaunchKernelGGL(attn_decode_kernel, grid, block, smem, s, a);
 }
 
 }  // namespace ptts

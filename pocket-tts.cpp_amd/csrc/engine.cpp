@@ -26,7 +26,9 @@ bool ends_with(const std::string& s, const std::string& suf) {
 // GEMM operands get a low-precision copy; tensors consumed by the scalar kernels stay f32 only.
 bool is_gemm_weight(const std::string& name) {
     if (!ends_with(name, ".w")) return false;
-    return name != "dec.up.w" && name != "dec.final.w" && name != "enc.conv0.w" && name != "lm.eos.w";
+    // the reference keeps the voice encoder in fp32 at every precision setting (src/pocket_tts.cpp:92)
+    if (name.rfind("enc.", 0) == 0) return false;
+    return name != "dec.up.w" && name != "dec.final.w" && name != "lm.eos.w";
 }
 
 size_t align256(size_t n) { return (n + 255) & ~static_cast<size_t>(255); }
@@ -165,25 +167,15 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
         std::string p = "lm.l" + std::to_string(i) + ".";
         lm_packed.push_back(PackedLayer{packed(p + "qkv.w"), packed(p + "out.w"), packed(p + "ff1.w"), packed(p + "ff2.w")});
     }
-    std::vector<const void*> tab(static_cast<size_t>(6) * nb);
     for (int i = 0; i < nb; ++i) {
         std::string p = "flow.b" + std::to_string(i) + ".";
-        tab[0 * nb + i] = packed(p + "fc1.w");
-        tab[1 * nb + i] = packed(p + "fc2.w");
-        tab[2 * nb + i] = f(p + "fc1.b");
-        tab[3 * nb + i] = f(p + "fc2.b");
-        tab[4 * nb + i] = f(p + "ln.g");
-        tab[5 * nb + i] = f(p + "ln.b");
+        flow_tabs.w_fc1.push_back(packed(p + "fc1.w"));
+        flow_tabs.w_fc2.push_back(packed(p + "fc2.w"));
+        flow_tabs.b_fc1.push_back(f(p + "fc1.b"));
+        flow_tabs.b_fc2.push_back(f(p + "fc2.b"));
+        flow_tabs.ln_g.push_back(f(p + "ln.g"));
+        flow_tabs.ln_b.push_back(f(p + "ln.b"));
     }
-    derived_.alloc(tab.size() * sizeof(void*));
-    PTTS_HIP(hipMemcpy(derived_.p, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice));
-    auto base = static_cast<const void* const*>(derived_.p);
-    d_w_fc1 = base + 0 * nb;
-    d_w_fc2 = base + 1 * nb;
-    d_b_fc1 = reinterpret_cast<const float* const*>(base + 2 * nb);
-    d_b_fc2 = reinterpret_cast<const float* const*>(base + 3 * nb);
-    d_ln_g = reinterpret_cast<const float* const*>(base + 4 * nb);
-    d_ln_b = reinterpret_cast<const float* const*>(base + 5 * nb);
 }
 
 const float* Model::f(const std::string& name) const {
@@ -313,6 +305,7 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     cemb.alloc(static_cast<size_t>(B) * C * 4);
     ymod.alloc(static_cast<size_t>(o.lsd_steps) * B * C * 4);
     mods.alloc(static_cast<size_t>(o.lsd_steps) * B * e.model().mod_width * 4);
+    flow_ws.alloc(flow_head_workspace_bytes(B, C, e.model().flow_wtype));
     // decoder activations
     zbuf.alloc(static_cast<size_t>(B) * kDecChunk * L * 4);
     qbuf.alloc(static_cast<size_t>(B) * (1 + kDecChunk) * M * 4);
@@ -525,7 +518,7 @@ Batch* Engine::acquire_batch(int B) {
 void Engine::transformer(const std::vector<TfLayer>& layers, float* kc, float* vc, long long layer_stride, int cap,
                          const int* pos_dev, int slot0, int nb, int rpb, float* X, int d, int heads, int ffn, float eps,
                          int window, const float* cos_tab, const float* sin_tab, int tab_len, const TfScratch& b, float* last_out,
-                         long long last_bs, int last_ld, hipStream_t st) {
+                         long long last_bs, int last_ld, hipStream_t st, bool split_a) {
     const int M = nb * rpb;
     for (size_t l = 0; l < layers.size(); ++l) {
         const TfLayer& w = layers[l];
@@ -534,6 +527,7 @@ void Engine::transformer(const std::vector<TfLayer>& layers, float* kc, float* v
         launch_layernorm(ln, st);
         GemmArgs g;
         g.A = b.h; g.lda = d; g.W = w.qkv.p; g.wtype = w.qkv.wtype; g.C = b.qkv; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d;
+        g.split_a = split_a;
         launch_gemm(g, st);
         RopeAppendArgs r;
         r.qkv = b.qkv; r.q_out = b.q; r.kcache = kc + l * layer_stride; r.vcache = vc + l * layer_stride;
@@ -546,17 +540,17 @@ void Engine::transformer(const std::vector<TfLayer>& layers, float* kc, float* v
         launch_attention(at, st);
         GemmArgs o;
         o.A = b.att; o.lda = d; o.W = w.out.p; o.wtype = w.out.wtype; o.C = X; o.ldc = d; o.R = X; o.ldr = d; o.colscale = w.ls1;
-        o.M = M; o.N = d; o.K = d;
+        o.M = M; o.N = d; o.K = d; o.split_a = split_a;
         launch_gemm(o, st);
         ln.g = w.ln2g; ln.b = w.ln2b;
         launch_layernorm(ln, st);
         GemmArgs f1;
         f1.A = b.h; f1.lda = d; f1.W = w.ff1.p; f1.wtype = w.ff1.wtype; f1.C = b.ff; f1.ldc = ffn; f1.act_pre = ACT_GELU;
-        f1.M = M; f1.N = ffn; f1.K = d;
+        f1.M = M; f1.N = ffn; f1.K = d; f1.split_a = split_a;
         launch_gemm(f1, st);
         GemmArgs f2;
         f2.A = b.ff; f2.lda = ffn; f2.W = w.ff2.p; f2.wtype = w.ff2.wtype; f2.R = X; f2.ldr = d; f2.colscale = w.ls2;
-        f2.M = M; f2.N = d; f2.K = ffn;
+        f2.M = M; f2.N = d; f2.K = ffn; f2.split_a = split_a;
         if (last_out && l + 1 == layers.size()) {
             f2.C = last_out; f2.c_bs = last_bs; f2.ldc = last_ld; f2.rpb = rpb;
             f2.r_bs = (long long)rpb * d; f2.a_bs = (long long)rpb * ffn;
@@ -576,7 +570,7 @@ void Engine::lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* 
     const auto& layers = hd_.lm;
     const long long layer_stride = static_cast<long long>(b.B) * b.lm_cap * s.d_model;
     transformer(layers, b.lm_k.f(), b.lm_v.f(), layer_stride, b.lm_cap, b.lm_pos.as<int>() + slot0, slot0, nb, rpb, X, s.d_model,
-                s.lm_heads, s.lm_ffn, s.lm_eps, 0, model_->lm_cos, model_->lm_sin, model_->lm_tab_len, b.scratch(), nullptr, 0, 0, stream_);
+                s.lm_heads, s.lm_ffn, s.lm_eps, 0, model_->lm_cos, model_->lm_sin, model_->lm_tab_len, b.scratch(), nullptr, 0, 0, stream_, true);
     if (adv_dev) launch_advance_pos_vec(b.lm_pos.as<int>() + slot0, adv_dev, nb, stream_);
     else launch_advance_pos(b.lm_pos.as<int>() + slot0, nb, rpb, stream_);
     for (int i = 0; i < nb; ++i) b.lm_pos_host[slot0 + i] += adv_host ? adv_host[i] : rpb;
@@ -598,7 +592,7 @@ static int pick_splits(int K, int kstep) {
 void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev) {
     const Spec& s = spec();
     const int B = b.B, D = s.d_model, F = s.lm_ffn;
-    const int wt = model_->flow_wtype, ct = wt == W_BF16 ? 1 : 0, kstep = wt == W_BF16 ? 32 : 16;
+    const int wt = model_->flow_wtype, kstep = wt == W_BF16 ? 32 : 16;
     for (int i = 0; i < B; ++i)
         if (b.lm_pos_host[i] + 1 > b.lm_cap) throw std::runtime_error("LM context exceeds the KV-cache capacity (voice + text + frames too long)");
     phase_begin(0);
@@ -606,40 +600,40 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
     const DevWeight& win = hd_.lm_in;
     GemmArgs g;
     g.A = b.seq_in.f(); g.lda = s.latent; g.W = win.p; g.wtype = win.wtype; g.C = b.x.f(); g.ldc = D;
-    g.M = B; g.N = D; g.K = s.latent;
+    g.M = B; g.N = D; g.K = s.latent; g.split_a = 1;
     launch_gemm(g, stream_);
     const int s_out = pick_splits(D, kstep), s_ff2 = pick_splits(F, kstep);
     const size_t pneed = static_cast<size_t>(std::max(s_out, s_ff2)) * B * D * 4;
     if (b.partial.bytes < pneed) b.partial.alloc(pneed);
     AddNormArgs an;
-    an.X = b.x.f(); an.ldx = D; an.M = B; an.D = D; an.wtype = wt; an.eps = s.lm_eps;
-    an.g = hd_.lm[0].ln1g; an.b = hd_.lm[0].ln1b; an.H = b.h.p; an.h_ct = ct;
+    an.X = b.x.f(); an.ldx = D; an.M = B; an.D = D; an.eps = s.lm_eps;
+    an.g = hd_.lm[0].ln1g; an.b = hd_.lm[0].ln1b; an.H = b.h.f();
     launch_add_norm(an, stream_);
     const long long layer_stride = static_cast<long long>(B) * b.lm_cap * D;
     for (int l = 0; l < s.lm_layers; ++l) {
         const TfLayer& w = hd_.lm[l];
         const Model::PackedLayer& pw = model_->lm_packed[l];
         SkinnyArgs q;
-        q.A = b.h.p; q.lda = D; q.Wp = pw.qkv; q.wtype = wt; q.M = B; q.N = 3 * D; q.K = D; q.C = b.qkv.p; q.ldc = 3 * D;
+        q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.wtype = wt; q.M = B; q.N = 3 * D; q.K = D; q.C = b.qkv.f(); q.ldc = 3 * D;
         launch_skinny_gemm(q, stream_);
         AttnDecodeArgs at;
         at.qkv = b.qkv.f(); at.kcache = b.lm_k.f() + l * layer_stride; at.vcache = b.lm_v.f() + l * layer_stride;
         at.pos = b.lm_pos.as<int>(); at.M = B; at.d = D; at.heads = s.lm_heads; at.cap = b.lm_cap; at.window = 0;
         at.cos_tab = model_->lm_cos; at.sin_tab = model_->lm_sin; at.tab_len = model_->lm_tab_len;
-        at.out = b.att.p; at.out_ct = ct; at.wtype = wt;
+        at.out = b.att.f();
         launch_attn_decode(at, stream_);
         SkinnyArgs o;
-        o.A = b.att.p; o.lda = D; o.Wp = pw.out; o.wtype = wt; o.M = B; o.N = D; o.K = D; o.splits = s_out; o.P = b.partial.f();
+        o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.wtype = wt; o.M = B; o.N = D; o.K = D; o.splits = s_out; o.P = b.partial.f();
         launch_skinny_gemm(o, stream_);
         AddNormArgs a1 = an;
         a1.P = b.partial.f(); a1.splits = s_out; a1.colscale = w.ls1; a1.g = w.ln2g; a1.b = w.ln2b;
         launch_add_norm(a1, stream_);
         SkinnyArgs f1;
-        f1.A = b.h.p; f1.lda = D; f1.Wp = pw.ff1; f1.wtype = wt; f1.M = B; f1.N = F; f1.K = D; f1.act = ACT_GELU;
-        f1.C = b.ff.p; f1.ldc = F; f1.c_ct = ct;
+        f1.A = b.h.f(); f1.lda = D; f1.Wp = pw.ff1; f1.wtype = wt; f1.M = B; f1.N = F; f1.K = D; f1.act = ACT_GELU;
+        f1.C = b.ff.f(); f1.ldc = F;
         launch_skinny_gemm(f1, stream_);
         SkinnyArgs f2;
-        f2.A = b.ff.p; f2.lda = F; f2.Wp = pw.ff2; f2.wtype = wt; f2.M = B; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.partial.f();
+        f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.wtype = wt; f2.M = B; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.partial.f();
         launch_skinny_gemm(f2, stream_);
         AddNormArgs a2 = an;
         a2.P = b.partial.f(); a2.splits = s_ff2; a2.colscale = w.ls2;
@@ -656,7 +650,7 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
     phase_end(0);
 }
 
-// lsd_steps Euler iterations for B rows: 3 small launches for the adaLN vectors, then the fused head.
+// lsd_steps Euler iterations for B rows: 3 small launches for the adaLN vectors, then the head's per-block chain.
 void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B) {
     const Spec& s = spec();
     const int C = s.flow_dim, N = opt_.lsd_steps;
@@ -664,19 +658,18 @@ void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long
     const DevWeight& wc = hd_.flow_cond;
     GemmArgs g;
     g.A = cond_dev; g.lda = s.d_model; g.W = wc.p; g.wtype = wc.wtype; g.C = b.cemb.f(); g.ldc = C; g.bias = hd_.flow_cond_b;
-    g.M = B; g.N = C; g.K = s.d_model;
+    g.M = B; g.N = C; g.K = s.d_model; g.split_a = 1;
     launch_gemm(g, stream_);
     launch_flow_mod_input(flow_te_.f(), b.cemb.f(), b.ymod.f(), N, B, C, stream_);
     GemmArgs m;
     m.A = b.ymod.f(); m.lda = C; m.W = model_->ada_all.p; m.wtype = model_->ada_all.wtype; m.C = b.mods.f(); m.ldc = model_->mod_width;
-    m.bias = model_->ada_all_b; m.M = N * B; m.N = model_->mod_width; m.K = C;
+    m.bias = model_->ada_all_b; m.M = N * B; m.N = model_->mod_width; m.K = C; m.split_a = 1;
     launch_gemm(m, stream_);
     FlowHeadArgs fa;
     fa.x0 = x0_dev; fa.x0_stride = x0_stride; fa.x_out = x_out_dev; fa.mods = b.mods.f(); fa.B = B; fa.L = s.latent; fa.C = C; fa.blocks = s.flow_blocks;
     fa.steps = N; fa.mod_width = model_->mod_width;
     fa.w_in = model_->flow_in_packed; fa.b_in = hd_.flow_in_b; fa.w_out = model_->flow_out_packed; fa.b_out = hd_.flow_out_b;
-    fa.w_fc1 = model_->d_w_fc1; fa.w_fc2 = model_->d_w_fc2; fa.b_fc1 = model_->d_b_fc1; fa.b_fc2 = model_->d_b_fc2;
-    fa.ln_g = model_->d_ln_g; fa.ln_b = model_->d_ln_b; fa.wtype = model_->flow_wtype; fa.eps = s.flow_eps;
+    fa.host_tabs = &model_->flow_tabs; fa.workspace = b.flow_ws.f(); fa.wtype = model_->flow_wtype; fa.eps = s.flow_eps;
     phase_begin(3);
     launch_flow_head(fa, stream_);
     phase_end(3);

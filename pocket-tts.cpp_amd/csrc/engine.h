@@ -47,10 +47,7 @@ public:
     int mod_width = 0;
     const float *lm_cos = nullptr, *lm_sin = nullptr; int lm_tab_len = 0;
     const float *mimi_cos = nullptr, *mimi_sin = nullptr; int mimi_tab_len = 0;
-    // per-block pointer tables for the fused flow head (device arrays)
-    const void* const* d_w_fc1 = nullptr; const void* const* d_w_fc2 = nullptr;
-    const float* const* d_b_fc1 = nullptr; const float* const* d_b_fc2 = nullptr;
-    const float* const* d_ln_g = nullptr; const float* const* d_ln_b = nullptr;
+    FlowHostTabs flow_tabs;      // per-block device pointers of the flow head (host arrays)
     const void *flow_in_packed = nullptr, *flow_out_packed = nullptr;  // fragment-major flow.in_proj.w / flow.final.lin.w
     // fragment-major copies of the weights the batched decode step streams (decode_kernels.hip)
     struct PackedLayer { const void *qkv, *out, *ff1, *ff2; };
@@ -65,7 +62,7 @@ private:
     Spec spec_;
     Precision prec_;
     std::map<std::string, Entry> entries_;
-    DevBuf blob_f32_, blob_lp_, derived_, rope_;
+    DevBuf blob_f32_, blob_lp_, rope_;
     std::vector<DevBuf> extra_;
 };
 
@@ -156,7 +153,7 @@ private:
     void transformer(const std::vector<TfLayer>& layers, float* kc, float* vc, long long layer_stride, int cap,
                      const int* pos_dev, int slot0, int nb, int rpb, float* X, int d, int heads, int ffn, float eps,
                      int window, const float* cos_tab, const float* sin_tab, int tab_len, const TfScratch& scratch,
-                     float* last_out, long long last_bs, int last_ld, hipStream_t st);
+                     float* last_out, long long last_bs, int last_ld, hipStream_t st, bool split_a = false);
     void lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* adv_dev = nullptr, const int* adv_host = nullptr);
     void lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev);
     void flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B);
@@ -224,7 +221,7 @@ public:
     DevBuf dx, dh, dqkv, dq, datt, dff;  // decoder-transformer scratch (separate: the decoder overlaps the frame loop)
     TfScratch dec_scratch() const { return TfScratch{dh.f(), dqkv.f(), dq.f(), datt.f(), dff.f()}; }
     // flow scratch
-    DevBuf cemb, ymod, mods;
+    DevBuf cemb, ymod, mods, flow_ws;
     DevBuf partial;   // split-K slabs of the decode step [splits][B][d_model] f32
     // audio out
     DevBuf audio;

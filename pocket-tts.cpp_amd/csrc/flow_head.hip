@@ -1,21 +1,28 @@
-// Fused LSD flow-matching head: all lsd_steps Euler iterations of the flow MLP in ONE launch.
+// LSD flow-matching head: lsd_steps Euler iterations of the adaLN MLP v(c, s, t, x)
+// (/root/reference/src/pocket_tts.cpp:414-451 run lsd_steps times per frame, :615-622 the x += v * dt loop).
 //
-// The reference runs the flow graph lsd_steps times per frame through ONNX Runtime and applies
-// x += v * dt on the host between calls (/root/reference/src/pocket_tts.cpp:414-451, 615-622).  Here a
-// workgroup owns 16 utterance rows and carries them through every layer of every Euler step with the
-// residual stream, the latent and the MFMA A-operands resident in LDS; nothing but weights and the
-// precomputed adaLN vectors is read from memory inside the loop, and there is no inter-workgroup
-// synchronisation.
+// Shape of the problem on MI355X: per frame the head is a chain of 2 * blocks * steps (= 120) dependent
+// [B x C] x [C x C] products with B ~ 64 rows.  One workgroup that walks the whole chain has to pull every
+// weight byte through one CU's L2 port (~40-100 GB/s), so the chain is cut where the data dependence forces
+// an exchange anyway and every link is spread over several CUs:
 //
-// gfx950 mapping: 1024 threads = 16 waves (4 per SIMD).  Every GEMM [16 x K] x [K x N] is cut into
-// 16-column MFMA tiles; wave w takes tiles w and w+16, so for N = 512 all waves issue their whole
-// weight slice (2 tiles x K/32 fragments of 1 KiB) back to back and ~0.5 MB is in flight per CU.
-// Weights are stored fragment-major (pack_flow_weight): one wave-level load = 1 KiB contiguous, each
-// lane receiving exactly its MFMA B fragment, straight from L2 into VGPRs (every wave reads a different
-// slice, so an LDS round trip would add nothing).  f32 weights use v_mfma_f32_16x16x4_f32, bf16 weights
-// v_mfma_f32_16x16x32_bf16.  The adaLN shift/scale/gate vectors depend only on the conditioning and
-// the Euler step index, never on x; they come from one batched GEMM ahead of this kernel and are
-// requested before the matrix loop of the layer that needs them, so their latency hides behind it.
+//   flow_block_kernel   one launch per residual block, grid (G, row groups of 16).  Workgroup g owns the
+//       column slice [g*C/G, (g+1)*C/G) of fc1 and the matching K-slice of fc2, so the pair needs no
+//       exchange in between; it leaves an f32 partial [16][C] of the block's output.  Every workgroup of a
+//       row group first rebuilds the same residual stream h = h_prev + gate * (sum of the previous block's G
+//       partials + bias) - a fixed-order, bitwise reproducible sum - and its LayerNorm/adaLN modulation.
+//       All weight fragments of the launch (C*C/G*2 elements per workgroup) are requested before anything
+//       else, so they stream in while the partials arrive and the norm is computed.
+//   flow_final_kernel   one launch per Euler step: last residual update, final adaLN, output projection,
+//       x += dt * v.
+//
+// A kernel boundary on one stream costs ~1.5 us on this part, about what an in-launch flag hand-off between
+// workgroups costs, and needs no co-residency or cache-scope protocol.
+//
+// Weights are fragment-major (pack_flow_weight): one wave-level load = 1 KiB contiguous, each lane receiving
+// exactly its MFMA B fragment.  f32 weights use v_mfma_f32_16x16x4_f32.  bf16 weights use
+// v_mfma_f32_16x16x32_bf16 with every f32 activation staged as two bf16 terms (hi = bf16(a), lo = bf16(a - hi))
+// and two MFMAs per fragment, so the only rounding relative to f32 arithmetic is the weights' own storage.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -28,53 +35,15 @@
 namespace ptts {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int kFlowThreads = 1024;
+constexpr int kFlowThreads = 512;
 constexpr int kFlowWaves = kFlowThreads / 64;
+constexpr int kMaxPieces = 4;  // float4 pieces per lane per row: C <= 1024
 
-template <typename WT> struct FlowTraits { static constexpr int pad = 4, kstep = 16; };
-template <> struct FlowTraits<__bf16> { static constexpr int pad = 8, kstep = 32; };
-
-// Two 16x16 output tiles (columns of tiles nt0 and nt1; nt1 < 0: none) of A[16][K] (LDS) x Wp (packed).
-template <typename WT>
-__device__ __forceinline__ void mm2(const WT* __restrict__ A, int lda, const WT* __restrict__ Wp, int K, int nt0, int nt1, int lane,
-                                    f32x4& acc0, f32x4& acc1) {
-    constexpr int KSTEP = FlowTraits<WT>::kstep;
-    const int KS = K / KSTEP;
-    const int r = lane & 15, g = lane >> 4;
-    const uint4* w0 = (const uint4*)Wp + (long long)nt0 * KS * 64 + lane;
-    const uint4* w1 = (const uint4*)Wp + (long long)(nt1 < 0 ? nt0 : nt1) * KS * 64 + lane;
-    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (std::is_same<WT, float>::value) {
-        const float* ap = A + r * lda + 4 * g;
-#pragma unroll 8
-        for (int ks = 0; ks < KS; ++ks) {
-            const float4 a4 = *(const float4*)(ap + ks * 16);
-            const uint4 u0 = w0[(long long)ks * 64];
-            const uint4 u1 = w1[(long long)ks * 64];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, __uint_as_float(u0.x), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, __uint_as_float(u1.x), acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, __uint_as_float(u0.y), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, __uint_as_float(u1.y), acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, __uint_as_float(u0.z), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, __uint_as_float(u1.z), acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, __uint_as_float(u0.w), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, __uint_as_float(u1.w), acc1, 0, 0, 0);
-        }
-    } else {
-        const __bf16* ap = A + r * lda + 8 * g;
-#pragma unroll 16
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 a8 = *(const bf16x8*)(ap + ks * 32);
-            const uint4 u0 = w0[(long long)ks * 64];
-            const uint4 u1 = w1[(long long)ks * 64];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, u0), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, u1), acc1, 0, 0, 0);
-        }
-    }
-}
+template <typename WT> struct FlowTraits { static constexpr int pad = 4, kstep = 16, planes = 1; };
+template <> struct FlowTraits<__bf16> { static constexpr int pad = 8, kstep = 32, planes = 2; };
 
 __device__ __forceinline__ float silu_dev(float v) { return v / (1.0f + expf(-v)); }
 
@@ -84,159 +53,362 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
-// LayerNorm (optional affine) + adaLN modulate of row `wave` of h -> A-operand buffer.
-// The modulation vectors are requested first so their memory latency overlaps the two reductions.
+// acc += A[16][k0 .. k0+kstep) * fragment, A in LDS (plane 0 = value or hi term, plane 1 = lo term)
 template <typename WT>
-__device__ __forceinline__ void ln_modulate(const float* h, int C, WT* dst, int ldd, const float* g, const float* b,
-                                            const float* mod_row, int shift_off, int scale_off, float eps, int row, int lane) {
-    constexpr int MAXI = 16;  // C <= 1024
-    const float* hr = h + row * C;
-    const int n = C / 64;
-    float sc[MAXI], sh[MAXI], v[MAXI];
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i)
-        if (i < n) { sc[i] = mod_row[scale_off + lane + 64 * i]; sh[i] = mod_row[shift_off + lane + 64 * i]; }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i)
-        if (i < n) { v[i] = hr[lane + 64 * i]; s += v[i]; }
-    const float mean = wsum(s) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i)
-        if (i < n) { float d = v[i] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(wsum(q) / (float)C + eps);
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i)
-        if (i < n) {
-            const int c = lane + 64 * i;
-            float y = (v[i] - mean) * rstd;
-            if (g) y = y * g[c] + b[c];
-            y = y * (1.0f + sc[i]) + sh[i];
-            dst[row * ldd + c] = (WT)y;
-        }
+__device__ __forceinline__ void mma_frag(const WT* A0, const WT* A1, int lda, int k0, const uint4 w, f32x4& acc, int lane) {
+    const int r = lane & 15, g4 = lane >> 4;
+    if constexpr (std::is_same<WT, float>::value) {
+        const float4 a4 = *(const float4*)(A0 + r * lda + k0 + 4 * g4);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, __uint_as_float(w.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, __uint_as_float(w.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, __uint_as_float(w.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, __uint_as_float(w.w), acc, 0, 0, 0);
+    } else {
+        const bf16x8 lo = *(const bf16x8*)(A1 + r * lda + k0 + 8 * g4);
+        const bf16x8 hi = *(const bf16x8*)(A0 + r * lda + k0 + 8 * g4);
+        const bf16x8 b8 = __builtin_bit_cast(bf16x8, w);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, b8, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, b8, acc, 0, 0, 0);
+    }
+}
+
+// one activation into the A-operand plane(s)
+template <typename WT>
+__device__ __forceinline__ void put_act(WT* A0, WT* A1, int idx, float v) {
+    if constexpr (std::is_same<WT, float>::value) {
+        A0[idx] = v;
+    } else {
+        const __bf16 hi = (__bf16)v;
+        A0[idx] = hi;
+        A1[idx] = (__bf16)(v - (float)hi);
+    }
 }
 
 template <typename WT>
-__global__ __launch_bounds__(kFlowThreads) void flow_head_kernel(FlowHeadArgs a) {
+__device__ __forceinline__ void put_act4(WT* A0, WT* A1, int idx, const float4 v) {
+    if constexpr (std::is_same<WT, float>::value) {
+        *(float4*)(A0 + idx) = v;
+    } else {
+        bf16x4 hi, lo;
+        hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+        lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+        lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+        *(bf16x4*)(A0 + idx) = hi;
+        *(bf16x4*)(A1 + idx) = lo;
+    }
+}
+
+// Row mapping of the element-wise phases: wave w owns rows 2w and 2w+1 of the 16-row group; lane l holds the
+// float4 pieces l, l + 64, ... of each row.  Everything below has compile-time trip counts and no data-dependent
+// branches around loads, so the compiler can put every load of a phase in flight before the first use.
+template <int C> struct RowMap {
+    static constexpr int PPR = C / 4, NP = (PPR + 63) / 64;
+    static __device__ __forceinline__ bool valid(int lane, int i) { return lane + 64 * i < PPR; }
+    static __device__ __forceinline__ int col(int lane, int i) { return valid(lane, i) ? 4 * (lane + 64 * i) : 0; }
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+
+// h = h_prev + gate * (part[0] + part[1] + ... + part[G-1] + bias), partials added in index order
+template <int C, int G>
+__device__ __forceinline__ void residual_update(float4 (&h)[2][RowMap<C>::NP], const float* h_prev, const float* part, long long part_gs,
+                                                const float* gate_base, int mod_width, const float* bias, int row0, int nrows,
+                                                int wave, int lane) {
+    using RM = RowMap<C>;
+    float4 hv[2][RM::NP], gt[2][RM::NP], bs[RM::NP], pt[G][2][RM::NP];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int lr = 2 * wave + rr;
+        const long long grow = row0 + (lr < nrows ? lr : nrows - 1);
+#pragma unroll
+        for (int i = 0; i < RM::NP; ++i) {
+            const int c = RM::col(lane, i);
+            hv[rr][i] = ld4(h_prev + grow * C + c);
+            gt[rr][i] = ld4(gate_base + grow * mod_width + c);
+#pragma unroll
+            for (int g = 0; g < G; ++g) pt[g][rr][i] = ld4(part + g * part_gs + grow * C + c);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RM::NP; ++i) bs[i] = ld4(bias + RM::col(lane, i));
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int i = 0; i < RM::NP; ++i) {
+            float4 sum = pt[0][rr][i];
+#pragma unroll
+            for (int g = 1; g < G; ++g) { sum.x += pt[g][rr][i].x; sum.y += pt[g][rr][i].y; sum.z += pt[g][rr][i].z; sum.w += pt[g][rr][i].w; }
+            float4 o = hv[rr][i];
+            o.x += gt[rr][i].x * (sum.x + bs[i].x); o.y += gt[rr][i].y * (sum.y + bs[i].y);
+            o.z += gt[rr][i].z * (sum.z + bs[i].z); o.w += gt[rr][i].w * (sum.w + bs[i].w);
+            h[rr][i] = o;
+        }
+}
+
+// LayerNorm (optional affine) + adaLN modulate of the wave's two rows -> A-operand planes
+template <typename WT, int C, bool AFFINE>
+__device__ __forceinline__ void norm_modulate(const float4 (&h)[2][RowMap<C>::NP], WT* A0, WT* A1, int lda, const float* ln_g,
+                                              const float* ln_b, const float* shift_base, const float* scale_base, int mod_width,
+                                              float eps, int row0, int nrows, int wave, int lane) {
+    using RM = RowMap<C>;
+    float4 sh[2][RM::NP], sc[2][RM::NP], g4[RM::NP], b4[RM::NP];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int lr = 2 * wave + rr;
+        const long long grow = row0 + (lr < nrows ? lr : nrows - 1);
+#pragma unroll
+        for (int i = 0; i < RM::NP; ++i) {
+            sh[rr][i] = ld4(shift_base + grow * mod_width + RM::col(lane, i));
+            sc[rr][i] = ld4(scale_base + grow * mod_width + RM::col(lane, i));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RM::NP; ++i) {
+        if constexpr (AFFINE) { g4[i] = ld4(ln_g + RM::col(lane, i)); b4[i] = ld4(ln_b + RM::col(lane, i)); }
+        else { g4[i] = make_float4(1.f, 1.f, 1.f, 1.f); b4[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < RM::NP; ++i)
+            if (RM::valid(lane, i)) s += (h[rr][i].x + h[rr][i].y) + (h[rr][i].z + h[rr][i].w);
+        const float mean = wsum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < RM::NP; ++i)
+            if (RM::valid(lane, i)) {
+                const float d0 = h[rr][i].x - mean, d1 = h[rr][i].y - mean, d2 = h[rr][i].z - mean, d3 = h[rr][i].w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        const float rstd = 1.0f / sqrtf(wsum(q) / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < RM::NP; ++i)
+            if (RM::valid(lane, i)) {
+                float4 y;
+                y.x = ((h[rr][i].x - mean) * rstd * g4[i].x + b4[i].x) * (1.0f + sc[rr][i].x) + sh[rr][i].x;
+                y.y = ((h[rr][i].y - mean) * rstd * g4[i].y + b4[i].y) * (1.0f + sc[rr][i].y) + sh[rr][i].y;
+                y.z = ((h[rr][i].z - mean) * rstd * g4[i].z + b4[i].z) * (1.0f + sc[rr][i].z) + sh[rr][i].z;
+                y.w = ((h[rr][i].w - mean) * rstd * g4[i].w + b4[i].w) * (1.0f + sc[rr][i].w) + sh[rr][i].w;
+                put_act4<WT>(A0, A1, (2 * wave + rr) * lda + 4 * (lane + 64 * i), y);
+            }
+    }
+}
+
+struct FlowBlockArgs {
+    const float* x_in = nullptr; long long x_stride = 0;   // first block of a step: latent rows feeding the input projection
+    const float* h_prev = nullptr; float* h_next = nullptr;           // [B][C]
+    const float* part_prev = nullptr; float* part_next = nullptr;     // [G][B][C]
+    const float* mods = nullptr;      // this Euler step's adaLN vectors [B][mod_width]
+    const float* prev_b2 = nullptr;   // fc2 bias of the previous block
+    int first = 0, blk = 0;
+    const void* w_in = nullptr; const float* b_in = nullptr;
+    const void* w1 = nullptr; const float* b1 = nullptr; const void* w2 = nullptr;
+    const float* ln_g = nullptr; const float* ln_b = nullptr;
+    int B = 0, mod_width = 0;
+    float eps = 1e-6f;
+};
+
+// C = flow_dim, G = column/K split, L = latent_dim; PF: request every weight fragment of the launch up front
+// (needs (C/16/G/8 * C/kstep + C/16/8 * C/kstep/G) * 4 VGPRs, so only for bf16 at C <= 512).
+template <typename WT, int C, int G, int L, bool PF>
+__global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int PAD = FlowTraits<WT>::pad;
-    const int C = a.C, L = a.L;
-    const int lda = C + PAD, ldx = L + PAD;
-    float* h = (float*)smem_raw;             // [16][C]   residual stream
-    float* xs = h + 16 * C;                  // [16][L]   latent
-    WT* abuf0 = (WT*)(xs + 16 * L);          // [16][lda] LN/modulate output
-    WT* abuf1 = abuf0 + 16 * lda;            // [16][lda] fc1 output
-    WT* abx = abuf1 + 16 * lda;              // [16][ldx] latent as A operand
+    using T = FlowTraits<WT>;
+    using RM = RowMap<C>;
+    constexpr int KSTEP = T::kstep, PAD = T::pad, PL = T::planes;
+    constexpr int NT = C / 16, NT1 = NT / G, KS = C / KSTEP, KS2 = KS / G, CS = C / G, KSL = L / KSTEP;
+    constexpr int lda = C + PAD, lda2 = CS + PAD, ldx = L + PAD;
+    constexpr int T1 = (NT1 + kFlowWaves - 1) / kFlowWaves, T2 = (NT + kFlowWaves - 1) / kFlowWaves;
+    static_assert(NT % G == 0 && KS % G == 0 && L % KSTEP == 0, "flow head: split does not tile");
+    float* hbuf = (float*)smem_raw;                         // [16][C]   (first block only)
+    WT* A0 = (WT*)(hbuf + 16 * C);                          // [PL][16][lda]
+    WT* A1 = A0 + (PL - 1) * 16 * lda;
+    WT* S0 = A0 + PL * 16 * lda;                            // [PL][16][lda2]  fc1 output slice
+    WT* S1 = S0 + (PL - 1) * 16 * lda2;
+    WT* X0 = S0 + PL * 16 * lda2;                           // [PL][16][ldx]
+    WT* X1 = X0 + (PL - 1) * 16 * ldx;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * 16;
+    const int g = blockIdx.x, row0 = blockIdx.y * 16;
     const int nrows = (a.B - row0) < 16 ? (a.B - row0) : 16;
-    const int crow = (lane >> 4) * 4, ccol = lane & 15;  // accumulator rows crow..crow+3, column ccol of a tile
-    const float dt = 1.0f / (float)a.steps;
-    const int NT = C / 16;
-    // global rows whose modulation vectors this lane needs: its LayerNorm row and its 4 accumulator rows
-    const int ln_grow = row0 + (wave < nrows ? wave : nrows - 1);
-    int acc_grow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc_grow[r] = row0 + ((crow + r) < nrows ? (crow + r) : nrows - 1);
+    const int crow = (lane >> 4) * 4, ccol = lane & 15;
+    const uint4* w1p = (const uint4*)a.w1 + ((long long)g * NT1 * KS) * 64 + lane;   // + (t*KS + ks)*64
+    const uint4* w2p = (const uint4*)a.w2 + ((long long)g * KS2) * 64 + lane;         // + (t*KS + ks2)*64
 
-    for (int i = tid; i < 16 * L; i += kFlowThreads) {
-        int r = i / L;
-        xs[i] = r < nrows ? a.x0[(long long)(row0 + r) * a.x0_stride + (i % L)] : 0.f;
+    uint4 wf1[PF ? T1 : 1][PF ? KS : 1], wf2[PF ? T2 : 1][PF ? KS2 : 1];
+    if constexpr (PF) {
+#pragma unroll
+        for (int i = 0; i < T1; ++i) {
+            const int t = (wave + kFlowWaves * i) < NT1 ? (wave + kFlowWaves * i) : NT1 - 1;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wf1[i][ks] = w1p[((long long)t * KS + ks) * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < T2; ++i) {
+            const int t = (wave + kFlowWaves * i) < NT ? (wave + kFlowWaves * i) : NT - 1;
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) wf2[i][ks] = w2p[((long long)t * KS + ks) * 64];
+        }
+    }
+
+    float bias1[T1];   // fc1 bias of this lane's output columns, requested with the weights
+#pragma unroll
+    for (int i = 0; i < T1; ++i) {
+        const int t = (wave + kFlowWaves * i) < NT1 ? (wave + kFlowWaves * i) : NT1 - 1;
+        bias1[i] = a.b1[g * CS + t * 16 + ccol];
+    }
+
+    // ---- residual stream rows of this wave
+    float4 h[2][RM::NP];
+    if (a.first) {
+        for (int i = tid; i < 16 * L; i += kFlowThreads) {
+            const int r = i / L, c = i % L;
+            const float v = r < nrows ? a.x_in[(long long)(row0 + r) * a.x_stride + c] : 0.f;
+            put_act<WT>(X0, X1, r * ldx + c, v);
+        }
+        __syncthreads();
+        uint4 wi[T2][KSL];
+        float bin[T2];
+#pragma unroll
+        for (int i = 0; i < T2; ++i) {
+            const int t = (wave + kFlowWaves * i) < NT ? (wave + kFlowWaves * i) : NT - 1;
+#pragma unroll
+            for (int ks = 0; ks < KSL; ++ks) wi[i][ks] = ((const uint4*)a.w_in)[((long long)t * KSL + ks) * 64 + lane];
+            bin[i] = a.b_in[t * 16 + ccol];
+        }
+#pragma unroll
+        for (int i = 0; i < T2; ++i) {
+            const int t = wave + kFlowWaves * i;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSL; ++ks) mma_frag<WT>(X0, X1, ldx, ks * KSTEP, wi[i][ks], acc, lane);
+            if (t < NT) {
+                const int c = t * 16 + ccol;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hbuf[(crow + r) * C + c] = acc[r] + bin[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int i = 0; i < RM::NP; ++i) h[rr][i] = ld4(hbuf + (2 * wave + rr) * C + RM::col(lane, i));
+    } else {
+        residual_update<C, G>(h, a.h_prev, a.part_prev, (long long)a.B * C, a.mods + (a.blk - 1) * 3 * C + 2 * C, a.mod_width, a.prev_b2,
+                              row0, nrows, wave, lane);
+    }
+    if (g == 0) {   // one workgroup of the row group keeps the stream for the next launch
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int i = 0; i < RM::NP; ++i)
+                if (2 * wave + rr < nrows && RM::valid(lane, i))
+                    *(float4*)(a.h_next + (long long)(row0 + 2 * wave + rr) * C + 4 * (lane + 64 * i)) = h[rr][i];
+    }
+    const float* mblk = a.mods + a.blk * 3 * C;
+    norm_modulate<WT, C, true>(h, A0, A1, lda, a.ln_g, a.ln_b, mblk, mblk + C, a.mod_width, a.eps, row0, nrows, wave, lane);
+    __syncthreads();
+
+    // ---- fc1: this workgroup's column slice, full K
+#pragma unroll
+    for (int i = 0; i < T1; ++i) {
+        const int t = wave + kFlowWaves * i;
+        const int tc = t < NT1 ? t : NT1 - 1;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 w;
+            if constexpr (PF) w = wf1[i][ks];
+            else w = w1p[((long long)tc * KS + ks) * 64];
+            mma_frag<WT>(A0, A1, lda, ks * KSTEP, w, acc, lane);
+        }
+        if (t < NT1) {
+            const int cl = t * 16 + ccol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) put_act<WT>(S0, S1, (crow + r) * lda2 + cl, silu_dev(acc[r] + bias1[i]));
+        }
     }
     __syncthreads();
 
-    for (int j = 0; j < a.steps; ++j) {
-        const float* mods_j = a.mods + (long long)j * a.B * a.mod_width;
-        const float* ln_mods = mods_j + (long long)ln_grow * a.mod_width;
-        for (int i = tid; i < 16 * L; i += kFlowThreads) abx[(i / L) * ldx + (i % L)] = (WT)xs[i];
-        __syncthreads();
-        // input projection: h = x W_in^T + b_in
-        for (int nt = wave; nt < NT; nt += 2 * kFlowWaves) {
-            const int nt1 = nt + kFlowWaves < NT ? nt + kFlowWaves : -1;
-            f32x4 acc0, acc1;
-            mm2<WT>(abx, ldx, (const WT*)a.w_in, L, nt, nt1, lane, acc0, acc1);
-            const int c0 = nt * 16 + ccol;
-            const float b0 = a.b_in[c0];
+    // ---- fc2: every output column, this workgroup's K-slice -> partial
+    float* pout = a.part_next + ((long long)g * a.B + row0) * C;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[(crow + r) * C + c0] = acc0[r] + b0;
-            if (nt1 >= 0) {
-                const int c1 = nt1 * 16 + ccol;
-                const float b1 = a.b_in[c1];
+    for (int i = 0; i < T2; ++i) {
+        const int t = wave + kFlowWaves * i;
+        const int tc = t < NT ? t : NT - 1;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h[(crow + r) * C + c1] = acc1[r] + b1;
-            }
+        for (int ks = 0; ks < KS2; ++ks) {
+            uint4 w;
+            if constexpr (PF) w = wf2[i][ks];
+            else w = w2p[((long long)tc * KS + ks) * 64];
+            mma_frag<WT>(S0, S1, lda2, ks * KSTEP, w, acc, lane);
         }
-        __syncthreads();
-        for (int blk = 0; blk < a.blocks; ++blk) {
-            const int moff = blk * 3 * C;
-            ln_modulate<WT>(h, C, abuf0, lda, a.ln_g[blk], a.ln_b[blk], ln_mods, moff, moff + C, a.eps, wave, lane);
-            __syncthreads();
-            const WT* w1 = (const WT*)a.w_fc1[blk];
-            const float* b1p = a.b_fc1[blk];
-            for (int nt = wave; nt < NT; nt += 2 * kFlowWaves) {
-                const int nt1 = nt + kFlowWaves < NT ? nt + kFlowWaves : -1;
-                f32x4 acc0, acc1;
-                mm2<WT>(abuf0, lda, w1, C, nt, nt1, lane, acc0, acc1);
-                const int c0 = nt * 16 + ccol;
-                const float bb0 = b1p[c0];
+        if (t < NT) {
+            const int c = t * 16 + ccol;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) abuf1[(crow + r) * lda + c0] = (WT)silu_dev(acc0[r] + bb0);
-                if (nt1 >= 0) {
-                    const int c1 = nt1 * 16 + ccol;
-                    const float bb1 = b1p[c1];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) abuf1[(crow + r) * lda + c1] = (WT)silu_dev(acc1[r] + bb1);
-                }
-            }
-            __syncthreads();
-            const WT* w2 = (const WT*)a.w_fc2[blk];
-            const float* b2p = a.b_fc2[blk];
-            for (int nt = wave; nt < NT; nt += 2 * kFlowWaves) {
-                const int nt1 = nt + kFlowWaves < NT ? nt + kFlowWaves : -1;
-                const int c0 = nt * 16 + ccol, c1 = (nt1 < 0 ? nt : nt1) * 16 + ccol;
-                // gates requested ahead of the matrix loop
-                float g0[4], g1[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float* gr = mods_j + (long long)acc_grow[r] * a.mod_width + moff + 2 * C;
-                    g0[r] = gr[c0];
-                    g1[r] = gr[c1];
-                }
-                f32x4 acc0, acc1;
-                mm2<WT>(abuf1, lda, w2, C, nt, nt1, lane, acc0, acc1);
-                const float bb0 = b2p[c0];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[(crow + r) * C + c0] += g0[r] * (acc0[r] + bb0);
-                if (nt1 >= 0) {
-                    const float bb1 = b2p[c1];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) h[(crow + r) * C + c1] += g1[r] * (acc1[r] + bb1);
-                }
-            }
-            __syncthreads();
+            for (int r = 0; r < 4; ++r)
+                if (crow + r < nrows) pout[(long long)(crow + r) * C + c] = acc[r];
         }
-        const int foff = a.blocks * 3 * C;
-        ln_modulate<WT>(h, C, abuf0, lda, nullptr, nullptr, ln_mods, foff, foff + C, a.eps, wave, lane);
-        __syncthreads();
-        for (int nt = wave; nt < L / 16; nt += kFlowWaves) {
-            f32x4 acc0, acc1;
-            mm2<WT>(abuf0, lda, (const WT*)a.w_out, C, nt, -1, lane, acc0, acc1);
-            const int col = nt * 16 + ccol;
-            const float bias = a.b_out[col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xs[(crow + r) * L + col] += (acc0[r] + bias) * dt;
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < 16 * L; i += kFlowThreads) {
-        int r = i / L;
-        if (r < nrows) a.x_out[(long long)(row0 + r) * L + (i % L)] = xs[i];
     }
 }
 
-// Reorders W[N][K] (row major) into the fragment-major layout mm2 streams: tile (nt, ks) holds, for
+struct FlowFinalArgs {
+    const float* h_prev = nullptr; const float* part_prev = nullptr;   // of the last block
+    const float* mods = nullptr; const float* prev_b2 = nullptr;
+    const float* x_in = nullptr; long long x_stride = 0;
+    float* x_out = nullptr;                                            // [B][L]
+    const void* w_out = nullptr; const float* b_out = nullptr;
+    int B = 0, blocks = 0, mod_width = 0;
+    float eps = 1e-6f, dt = 0.f;
+};
+
+// Last residual update, final adaLN, output projection (K split over the waves, summed through LDS in wave
+// order), x_out = x_in + dt * v.
+template <typename WT, int C, int G, int L>
+__global__ __launch_bounds__(kFlowThreads) void flow_final_kernel(FlowFinalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using T = FlowTraits<WT>;
+    using RM = RowMap<C>;
+    constexpr int KSTEP = T::kstep, PAD = T::pad, PL = T::planes;
+    constexpr int lda = C + PAD, KS = C / KSTEP, NTL = L / 16;
+    constexpr int KPARTS = kFlowWaves / NTL, KSP = KS / KPARTS;   // waves per output tile, k-steps per wave
+    static_assert(kFlowWaves % NTL == 0 && KS % KPARTS == 0, "flow head: output projection does not tile");
+    WT* A0 = (WT*)smem_raw;
+    WT* A1 = A0 + (PL - 1) * 16 * lda;
+    float* red = (float*)(A0 + PL * 16 * lda);   // [waves][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * 16;
+    const int nrows = (a.B - row0) < 16 ? (a.B - row0) : 16;
+    const int t = wave % NTL, kp = wave / NTL;
+    uint4 wo[KSP];
+#pragma unroll
+    for (int ks = 0; ks < KSP; ++ks) wo[ks] = ((const uint4*)a.w_out)[((long long)t * KS + kp * KSP + ks) * 64 + lane];
+    float4 h[2][RM::NP];
+    residual_update<C, G>(h, a.h_prev, a.part_prev, (long long)a.B * C, a.mods + (a.blocks - 1) * 3 * C + 2 * C, a.mod_width, a.prev_b2,
+                          row0, nrows, wave, lane);
+    const float* mfin = a.mods + a.blocks * 3 * C;
+    norm_modulate<WT, C, false>(h, A0, A1, lda, nullptr, nullptr, mfin, mfin + C, a.mod_width, a.eps, row0, nrows, wave, lane);
+    __syncthreads();
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSP; ++ks) mma_frag<WT>(A0, A1, lda, (kp * KSP + ks) * KSTEP, wo[ks], acc, lane);
+    *(f32x4*)(red + wave * 256 + lane * 4) = acc;
+    __syncthreads();
+    for (int i = tid; i < 16 * L; i += kFlowThreads) {
+        const int r = i / L, c = i % L;
+        if (r >= nrows) continue;
+        const int tt = c / 16, ln = (r / 4) * 16 + (c % 16), ri = r % 4;   // accumulator of tile tt: lane ln, element ri
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < KPARTS; ++k) v += red[(k * NTL + tt) * 256 + ln * 4 + ri];
+        const long long row = row0 + r;
+        a.x_out[row * L + c] = a.x_in[row * a.x_stride + c] + (v + a.b_out[c]) * a.dt;
+    }
+}
+
+// Reorders W[N][K] (row major) into the fragment-major layout the kernels stream: tile (nt, ks) holds, for
 // lane l, the `per` consecutive k-values ks*kstep + per*(l>>4) .. of output column nt*16 + (l&15).
 std::vector<unsigned char> pack_flow_weight(const float* W, int N, int K, int wtype) {
     const bool bf = wtype == W_BF16;
@@ -263,20 +435,75 @@ std::vector<unsigned char> pack_flow_weight(const float* W, int N, int K, int wt
     return out;
 }
 
+constexpr int kFlowSplit = 4;
+
+size_t flow_head_workspace_bytes(int B, int C, int wtype) {
+    (void)wtype;
+    return ((size_t)2 * B * C + (size_t)2 * kFlowSplit * B * C) * sizeof(float);
+}
+
+template <typename K>
+static void set_lds_limit(K kernel, size_t smem) {
+    // hipFuncSetAttribute is per device; remember where it has been applied
+    static bool done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (smem > 64 * 1024 && dev >= 0 && dev < 64 && !done[dev]) {
+        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done[dev] = true;
+    }
+}
+
+template <typename WT, int C, bool PF>
+static void run_chain(const FlowHeadArgs& a, hipStream_t s) {
+    constexpr int G = kFlowSplit, L = 32;
+    using T = FlowTraits<WT>;
+    const int B = a.B, RG = (B + 15) / 16;
+    const size_t smem_block = (size_t)16 * C * 4 + (size_t)T::planes * 16 * ((C + T::pad) + (C / G + T::pad) + (L + T::pad)) * sizeof(WT);
+    const size_t smem_final = (size_t)T::planes * 16 * (C + T::pad) * sizeof(WT) + (size_t)kFlowWaves * 256 * 4;
+    auto kb = flow_block_kernel<WT, C, G, L, PF>;
+    auto kf = flow_final_kernel<WT, C, G, L>;
+    set_lds_limit(kb, smem_block);
+    set_lds_limit(kf, smem_final);
+    float* hb[2] = {a.workspace, a.workspace + (size_t)B * C};
+    float* pb[2] = {a.workspace + (size_t)2 * B * C, a.workspace + (size_t)2 * B * C + (size_t)G * B * C};
+    const FlowHostTabs& tabs = *a.host_tabs;
+    int cur = 0;
+    for (int j = 0; j < a.steps; ++j) {
+        const float* mods_j = a.mods + (size_t)j * B * a.mod_width;
+        const float* x_in = j == 0 ? a.x0 : a.x_out;
+        const long long x_stride = j == 0 ? a.x0_stride : (long long)L;
+        for (int blk = 0; blk < a.blocks; ++blk) {
+            FlowBlockArgs fb;
+            fb.x_in = x_in; fb.x_stride = x_stride;
+            fb.h_prev = hb[cur ^ 1]; fb.h_next = hb[cur]; fb.part_prev = pb[cur ^ 1]; fb.part_next = pb[cur];
+            fb.mods = mods_j; fb.prev_b2 = blk ? tabs.b_fc2[blk - 1] : nullptr;
+            fb.first = blk == 0; fb.blk = blk;
+            fb.w_in = a.w_in; fb.b_in = a.b_in; fb.w1 = tabs.w_fc1[blk]; fb.b1 = tabs.b_fc1[blk]; fb.w2 = tabs.w_fc2[blk];
+            fb.ln_g = tabs.ln_g[blk]; fb.ln_b = tabs.ln_b[blk];
+            fb.B = B; fb.mod_width = a.mod_width; fb.eps = a.eps;
+            hipLaunchKernelGGL(kb, dim3(G, RG), dim3(kFlowThreads), smem_block, s, fb);
+            cur ^= 1;
+        }
+        FlowFinalArgs ff;
+        ff.h_prev = hb[cur ^ 1]; ff.part_prev = pb[cur ^ 1]; ff.mods = mods_j; ff.prev_b2 = tabs.b_fc2[a.blocks - 1];
+        ff.x_in = x_in; ff.x_stride = x_stride; ff.x_out = a.x_out; ff.w_out = a.w_out; ff.b_out = a.b_out;
+        ff.B = B; ff.blocks = a.blocks; ff.mod_width = a.mod_width; ff.eps = a.eps; ff.dt = 1.0f / (float)a.steps;
+        hipLaunchKernelGGL(kf, dim3(RG), dim3(kFlowThreads), smem_final, s, ff);
+    }
+}
+
 void launch_flow_head(const FlowHeadArgs& a, hipStream_t s) {
     if (a.B <= 0) return;
-    if (a.C % 64 || a.C > 1024 || a.L % 32 || a.steps <= 0)
-        throw std::runtime_error("flow head: flow_dim must be a multiple of 64 (<= 1024) and latent_dim a multiple of 32");
-    const int wbytes = a.wtype == W_BF16 ? 2 : 4;
-    const int pad = a.wtype == W_BF16 ? 8 : 4;
-    size_t smem = (size_t)16 * a.C * 4 + (size_t)16 * a.L * 4 + (size_t)2 * 16 * (a.C + pad) * wbytes + (size_t)16 * (a.L + pad) * wbytes;
-    dim3 grid((a.B + 15) / 16), block(kFlowThreads);
-    if (a.wtype == W_BF16) {
-        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)flow_head_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(flow_head_kernel<__bf16>, grid, block, smem, s, a);
-    } else {
-        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)flow_head_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(flow_head_kernel<float>, grid, block, smem, s, a);
+    if (a.L != 32 || a.steps <= 0 || a.blocks <= 0) throw std::runtime_error("flow head: latent_dim must be 32");
+    if (!a.workspace || !a.host_tabs) throw std::runtime_error("flow head: workspace and host pointer tables are required");
+    const bool bf = a.wtype == W_BF16;
+    switch (a.C) {
+        case 128: bf ? run_chain<__bf16, 128, true>(a, s) : run_chain<float, 128, false>(a, s); break;
+        case 256: bf ? run_chain<__bf16, 256, true>(a, s) : run_chain<float, 256, false>(a, s); break;
+        case 512: bf ? run_chain<__bf16, 512, true>(a, s) : run_chain<float, 512, false>(a, s); break;
+        case 1024: bf ? run_chain<__bf16, 1024, false>(a, s) : run_chain<float, 1024, false>(a, s); break;
+        default: throw std::runtime_error("flow head: flow_dim must be 128, 256, 512 or 1024");
     }
 }
 

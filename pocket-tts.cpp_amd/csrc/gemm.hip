@@ -4,7 +4,9 @@
 //
 // gfx950 mapping: 256 threads = 4 waves in a 2x2 grid; each wave owns (BM/2)x(BN/2) of the block tile
 // as 32x32 MFMA tiles.  f32 weights use v_mfma_f32_32x32x2_f32 (an exact f32 FMA chain), bf16 weights
-// use v_mfma_f32_32x32x16_bf16 with activations rounded to bf16 while they are staged into LDS.
+// use v_mfma_f32_32x32x16_bf16 with activations converted to bf16 while they are staged into LDS: either
+// rounded once (SPLIT = false) or as the two-term sum hi + lo (SPLIT = true, two MFMAs per tile), which
+// keeps ~16 mantissa bits of the activation so that only the weights' own bf16 storage rounds.
 // Global loads for tile k+1 are issued before the MFMAs of tile k and written to LDS after them.
 #include <hip/hip_runtime.h>
 
@@ -31,13 +33,14 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 constexpr int BK = 32;
 
-template <typename WT, int BM, int BN>
+template <typename WT, int BM, int BN, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     constexpr bool kBf16 = !__is_same(WT, float);
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int LDSK = kBf16 ? (BK + 8) : (BK + 1);  // element stride of one LDS row
     using LT = typename std::conditional<kBf16, __bf16, float>::type;
     __shared__ __attribute__((aligned(16))) LT As[BM * LDSK];
+    __shared__ __attribute__((aligned(16))) LT Al[SPLIT ? BM * LDSK : 8];  // lo terms
     __shared__ __attribute__((aligned(16))) LT Ws[BN * LDSK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -92,6 +95,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
                 bf16x4 p;
                 p[0] = (__bf16)v.x; p[1] = (__bf16)v.y; p[2] = (__bf16)v.z; p[3] = (__bf16)v.w;
                 *(bf16x4*)&As[row * LDSK + a_c4 * 4] = p;
+                if constexpr (SPLIT) {
+                    bf16x4 q;
+                    q[0] = (__bf16)(v.x - (float)p[0]); q[1] = (__bf16)(v.y - (float)p[1]);
+                    q[2] = (__bf16)(v.z - (float)p[2]); q[3] = (__bf16)(v.w - (float)p[3]);
+                    *(bf16x4*)&Al[row * LDSK + a_c4 * 4] = q;
+                }
             } else {
                 float* d = (float*)&As[row * LDSK + a_c4 * 4];
                 d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
@@ -127,18 +136,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         if constexpr (kBf16) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8 af[TM], bf[TN];
+                bf16x8 af[TM], al[TM], bf[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) {
                     af[i] = *(const bf16x8*)&As[(wr * TM * 32 + i * 32 + lr) * LDSK + ks * 16 + lh * 8];
+                    if constexpr (SPLIT) al[i] = *(const bf16x8*)&Al[(wr * TM * 32 + i * 32 + lr) * LDSK + ks * 16 + lh * 8];
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     bf[j] = *(const bf16x8*)&Ws[(wc * TN * 32 + j * 32 + lr) * LDSK + ks * 16 + lh * 8];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (SPLIT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bf[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    }
             }
         } else {
 #pragma unroll
@@ -198,10 +211,12 @@ void launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.wtype == W_BF16) {
         if (big) {
             dim3 grid((a.M + 127) / 128, (a.N + 127) / 128);
-            hipLaunchKernelGGL((gemm_kernel<__bf16, 128, 128>), grid, block, 0, s, a);
+            if (a.split_a) hipLaunchKernelGGL((gemm_kernel<__bf16, 128, 128, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((gemm_kernel<__bf16, 128, 128, false>), grid, block, 0, s, a);
         } else {
             dim3 grid((a.M + 63) / 64, (a.N + 63) / 64);
-            hipLaunchKernelGGL((gemm_kernel<__bf16, 64, 64>), grid, block, 0, s, a);
+            if (a.split_a) hipLaunchKernelGGL((gemm_kernel<__bf16, 64, 64, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((gemm_kernel<__bf16, 64, 64, false>), grid, block, 0, s, a);
         }
     } else if (a.wtype == W_F32) {
         if (big) {

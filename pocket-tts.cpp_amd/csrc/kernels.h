@@ -30,6 +30,7 @@ struct GemmArgs {
     int rpb = 1 << 30;
     int M = 0, N = 0, K = 0;
     int a_act = ACT_NONE, act_pre = ACT_NONE;
+    int split_a = 0;  // bf16 weights only: stage A as hi + lo bf16 terms (two MFMAs per tile) instead of rounding it once
 };
 void launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -99,56 +100,59 @@ void launch_conv_from_mono(const float* audio, long long a_bs, const int* len, i
 // Carry history: for each b, rows [T, T+H) of buf[b] move to rows [0, H)  (row length C floats).
 void launch_shift_history(float* buf, long long bs, int T, int H, int C, int B, hipStream_t s);
 
-// ---- fused LSD flow head ------------------------------------------------------------------------
-// One persistent launch runs all `steps` Euler iterations of the flow MLP for every row:
+// ---- LSD flow head --------------------------------------------------------------------------------
+// All `steps` Euler iterations of the flow MLP for every row:
 //   x <- x + dt * v(c, s_j, t_j, x),  j = 0..steps-1
-// mods[j][b][:] holds the precomputed adaLN vectors of Euler step j (they depend on c and j only):
-//   per block (shift, scale, gate) x C, then final (shift, scale) x C.
+// as a chain of per-block launches (flow_head.hip).  mods[j][b][:] holds the precomputed adaLN vectors of
+// Euler step j (they depend on c and j only): per block (shift, scale, gate) x C, then final (shift, scale) x C.
+struct FlowHostTabs {   // host arrays of per-block device pointers
+    std::vector<const void*> w_fc1, w_fc2;           // pack_flow_weight layout, [C][C]
+    std::vector<const float*> b_fc1, b_fc2, ln_g, ln_b;
+};
 struct FlowHeadArgs {
     const float* x0 = nullptr;    // start points, row b at x0 + b * x0_stride
     long long x0_stride = 0;
-    float* x_out = nullptr;       // [B][L]
+    float* x_out = nullptr;       // [B][L]; also carries x between Euler steps (must not alias x0)
     const float* mods = nullptr;  // [steps][B][mod_width]
     int B = 0, L = 0, C = 0, blocks = 0, steps = 0, mod_width = 0;
-    // all weights below are in pack_flow_weight layout
-    const void* w_in = nullptr; const float* b_in = nullptr;       // [C][L]
-    const void* const* w_fc1 = nullptr; const float* const* b_fc1 = nullptr;  // device arrays of per-block pointers
-    const void* const* w_fc2 = nullptr; const float* const* b_fc2 = nullptr;
-    const float* const* ln_g = nullptr; const float* const* ln_b = nullptr;
-    const void* w_out = nullptr; const float* b_out = nullptr;     // [L][C]
+    const void* w_in = nullptr; const float* b_in = nullptr;       // [C][L], pack_flow_weight layout
+    const void* w_out = nullptr; const float* b_out = nullptr;     // [L][C], pack_flow_weight layout
+    const FlowHostTabs* host_tabs = nullptr;
+    float* workspace = nullptr;   // flow_head_workspace_bytes(B, C, wtype) bytes
     int wtype = W_F32;
     float eps = 1e-6f;
 };
 void launch_flow_head(const FlowHeadArgs& a, hipStream_t s);
+size_t flow_head_workspace_bytes(int B, int C, int wtype);
 // Host-side reorder of a flow-head weight W[N][K] into the fragment-major layout the kernel streams.
 std::vector<unsigned char> pack_flow_weight(const float* W, int N, int K, int wtype);
 
 // ---- batched decode step (decode_kernels.hip) -----------------------------------------------------
-// C[M][N] = A[M][K] * W^T with A already in the compute type (f32 or bf16) and W fragment-major
-// (pack_flow_weight layout).  splits == 1 and P == null: C = act(acc + bias) stored as f32 or compute
-// type.  P != null: K is cut into `splits` slices and slice s writes the raw f32 slab P[s][M][N].
+// C[M][N] = A[M][K] * W^T with f32 A and W fragment-major (pack_flow_weight layout, f32 or bf16).
+// splits == 1 and P == null: C = act(acc + bias).  P != null: K is cut into `splits` slices and slice s
+// writes the raw f32 slab P[s][M][N].
 struct SkinnyArgs {
-    const void* A = nullptr; int lda = 0;
+    const float* A = nullptr; int lda = 0;
     const void* Wp = nullptr; int wtype = W_F32;
     int M = 0, N = 0, K = 0, splits = 1;
     const float* bias = nullptr; int act = ACT_NONE;
-    void* C = nullptr; int ldc = 0; int c_ct = 0;
+    float* C = nullptr; int ldc = 0;
     float* P = nullptr;
 };
 void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s);
 
 // Per row m: X[m] += colscale * (sum_s P[s][m] + pbias)  (skipped when P is null), then
-// y = LayerNorm(X[m]; g, b) -> H (compute type or f32), optional f32 copy H32, optional dot_out[m] = y . dot_w + dot_b,
+// y = LayerNorm(X[m]; g, b) -> H, optional second copy H32, optional dot_out[m] = y . dot_w + dot_b,
 // optional pos[m] += pos_delta.  g == null: no normalisation outputs.
 struct AddNormArgs {
     float* X = nullptr; int ldx = 0;
     const float* P = nullptr; int splits = 0;
     const float* colscale = nullptr; const float* pbias = nullptr;
     const float* g = nullptr; const float* b = nullptr; float eps = 1e-5f;
-    void* H = nullptr; int h_ct = 0; float* H32 = nullptr;
+    float* H = nullptr; float* H32 = nullptr;
     const float* dot_w = nullptr; const float* dot_b = nullptr; float* dot_out = nullptr;
     int* pos = nullptr; int pos_delta = 0;
-    int M = 0, D = 0; int wtype = W_F32;
+    int M = 0, D = 0;
 };
 void launch_add_norm(const AddNormArgs& a, hipStream_t s);
 
@@ -160,7 +164,7 @@ struct AttnDecodeArgs {
     const int* pos = nullptr; int slot0 = 0;
     int M = 0, d = 0, heads = 0, cap = 0, window = 0;
     const float* cos_tab = nullptr; const float* sin_tab = nullptr; int tab_len = 0;
-    void* out = nullptr; int out_ct = 0; int wtype = W_F32;
+    float* out = nullptr;
 };
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
 

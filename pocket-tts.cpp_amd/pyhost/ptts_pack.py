@@ -281,7 +281,8 @@ def make_pack(path: str, spec: Spec, seed: int = 1234, eos_bias: float = -20.0,
     return w
 
 
-F32_ONLY_WEIGHTS = ("dec.up.w", "dec.final.w", "enc.conv0.w", "lm.eos.w")
+F32_ONLY_WEIGHTS = ("dec.up.w", "dec.final.w", "lm.eos.w")
+F32_ONLY_PREFIXES = ("enc.", "flow.time")   # voice encoder (fp32 at every precision) and the host-evaluated time embeddings
 
 
 def bf16_round(a: np.ndarray) -> np.ndarray:
@@ -293,8 +294,11 @@ def bf16_round(a: np.ndarray) -> np.ndarray:
 
 def bf16_model(weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     """The model the bf16 engine actually holds: matrix weights rounded to bf16, everything else
-    (biases, norms, embedding table, depthwise/1-channel convs, EOS head) left in float32."""
-    return {k: (bf16_round(v) if k.endswith(".w") and k not in F32_ONLY_WEIGHTS else v) for k, v in weights.items()}
+    (biases, norms, embedding table, depthwise/1-channel convs, EOS head, time-embedding MLP, voice encoder)
+    left in float32."""
+    def rounded(k):
+        return k.endswith(".w") and k not in F32_ONLY_WEIGHTS and not k.startswith(F32_ONLY_PREFIXES)
+    return {k: (bf16_round(v) if rounded(k) else v) for k, v in weights.items()}
 
 
 if __name__ == "__main__":
