@@ -63,6 +63,7 @@ struct AttentionArgs {
     int M = 0, d = 0, heads = 0, cap = 0, window = 0;  // window <= 0: all earlier keys
 };
 void launch_attention(const AttentionArgs& a, hipStream_t s);
+void launch_attention_tiled(const AttentionArgs& a, hipStream_t s);   // rpb rows per slot, M % rpb == 0
 
 // pos[i] += delta for i < n
 void launch_advance_pos(int* pos, int n, int delta, hipStream_t s);

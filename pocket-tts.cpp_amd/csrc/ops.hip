@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttentionArgs a) {
 void launch_attention(const AttentionArgs& a, hipStream_t s) {
     if (a.M <= 0) return;
     if (a.d != a.heads * 64) throw std::runtime_error("attention: head dimension must be 64");
+    if (a.rpb >= 16 && a.M % a.rpb == 0) { launch_attention_tiled(a, s); return; }   // many rows per slot: MFMA tiles
     long long items = (long long)a.M * a.heads;
     size_t smem = (size_t)4 * a.cap * sizeof(float);
     if (smem > 160 * 1024) throw std::runtime_error("attention: context capacity too large for LDS score buffer");

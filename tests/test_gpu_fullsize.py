@@ -84,7 +84,7 @@ def test_full_streaming_first_chunk(full):
     assert total == 10 * 1920 and [len(c) for c, _ in chunks] == [5 * 1920, 5 * 1920]
     assert [f for _, f in chunks] == [0, 0]     # a stream that ends on a chunk boundary never reports is_final
     off = eng.generate_ids(full["ids"][:1], full["voices"][:1])[0]
-    np.testing.assert_array_equal(np.concatenate([c for c, _ in chunks]), off["audio"])
+    np.testing.assert_allclose(np.concatenate([c for c, _ in chunks]), off["audio"], rtol=0, atol=2e-5)
     _note(f"fp32 full size streaming: first 5-frame chunk after {t_first * 1e3:.1f} ms")
     eng.close()
 

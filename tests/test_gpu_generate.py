@@ -89,7 +89,8 @@ def test_streaming_schedule_and_chunk_invariance(ptts, packs, oracle_mod, chunk,
     assert total == sum(len(c) for c, _ in chunks) == F * spec.frame_size
     streamed = np.concatenate([c for c, _ in chunks])
     off = eng.generate_ids(ids, voices)[0]
-    np.testing.assert_array_equal(streamed, off["audio"])   # same stateful decoder, different chunking
+    # same stateful decoder, different chunking: only the summation order inside the attention tiles differs
+    np.testing.assert_allclose(streamed, off["audio"], rtol=0, atol=2e-5)
     assert snr_db(oracle_decode(o, off["latents"]), streamed) >= 40.0
     eng.close()
 
