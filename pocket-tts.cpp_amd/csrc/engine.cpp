@@ -304,7 +304,7 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     latents.alloc(static_cast<size_t>(B) * o.max_frames * L * 4);
     ids.alloc(static_cast<size_t>(std::max(o.max_text_tokens, 1)) * 8);
     const int C = s.flow_dim;
-    cemb.alloc(static_cast<size_t>(B) * C * 4);
+    cemb.alloc(static_cast<size_t>(16) * B * C * 4);   // up to 16 K-slice slabs
     ymod.alloc(static_cast<size_t>(o.lsd_steps) * B * C * 4);
     mods.alloc(static_cast<size_t>(o.lsd_steps) * B * e.model().mod_width * 4);
     flow_ws.alloc(flow_head_workspace_bytes(B, C, e.model().flow_wtype));
@@ -679,12 +679,14 @@ void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long
     const Spec& s = spec();
     const int C = s.flow_dim, N = opt_.lsd_steps;
     phase_begin(1);
-    const DevWeight& wc = hd_.flow_cond;
-    GemmArgs g;
-    g.A = cond_dev; g.lda = s.d_model; g.W = wc.p; g.wtype = wc.wtype; g.C = b.cemb.f(); g.ldc = C; g.bias = hd_.flow_cond_b;
-    g.M = B; g.N = C; g.K = s.d_model; g.split_a = 1;
-    launch_gemm(g, stream_);
-    launch_flow_mod_input(flow_te_.f(), b.cemb.f(), b.ymod.f(), N, B, C, stream_);
+    // conditioning embedding as K-slice slabs (skinny product), summed inside the next kernel
+    const int wt = model_->flow_wtype;
+    const int cs = pick_splits(s.d_model, wt == W_BF16 ? 32 : 16);
+    SkinnyArgs g;
+    g.A = cond_dev; g.lda = s.d_model; g.Wp = model_->flow_cond_packed; g.wtype = wt; g.M = B; g.N = C; g.K = s.d_model;
+    g.splits = cs; g.P = b.cemb.f();
+    launch_skinny_gemm(g, stream_);
+    launch_flow_mod_input(flow_te_.f(), b.cemb.f(), cs, hd_.flow_cond_b, b.ymod.f(), N, B, C, stream_);
     GemmArgs m;
     m.A = b.ymod.f(); m.lda = C; m.W = model_->ada_all.p; m.wtype = model_->ada_all.wtype; m.C = b.mods.f(); m.ldc = model_->mod_width;
     m.bias = model_->ada_all_b; m.M = N * B; m.N = model_->mod_width; m.K = C; m.split_a = 1;

@@ -169,7 +169,7 @@ struct AttnDecodeArgs {
 };
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
 
-// Y[j][b][:] = silu(te[j][:] + cemb[b][:])   (input rows of the stacked adaLN GEMM)
-void launch_flow_mod_input(const float* te, const float* cemb, float* Y, int steps, int B, int C, hipStream_t s);
+// Y[j][b][:] = silu(te[j][:] + sum_s cemb[s][b][:] + bias)   (input rows of the stacked adaLN GEMM)
+void launch_flow_mod_input(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C, hipStream_t s);
 
 }  // namespace ptts

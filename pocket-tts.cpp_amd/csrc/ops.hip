@@ -339,19 +339,24 @@ void launch_shift_history(float* buf, long long bs, int T, int H, int C, int B, 
     hipLaunchKernelGGL(shift_history_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, buf, bs, T, H, C);
 }
 
-__global__ void flow_mod_input_kernel(const float* te, const float* cemb, float* Y, int steps, int B, int C) {
+// cemb is given as `splits` K-slice slabs [splits][B][C] of the conditioning product plus its bias; the slabs are
+// added in slice order.
+__global__ void flow_mod_input_kernel(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)steps * B * C) return;
     int c = (int)(i % C);
     long long jb = i / C;
     int b = (int)(jb % B), j = (int)(jb / B);
-    float v = te[(long long)j * C + c] + cemb[(long long)b * C + c];
+    float e = cemb[(long long)b * C + c];
+    for (int s = 1; s < splits; ++s) e += cemb[((long long)s * B + b) * C + c];
+    if (bias) e += bias[c];
+    float v = te[(long long)j * C + c] + e;
     Y[i] = v / (1.0f + expf(-v));
 }
-void launch_flow_mod_input(const float* te, const float* cemb, float* Y, int steps, int B, int C, hipStream_t s) {
+void launch_flow_mod_input(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C, hipStream_t s) {
     long long n = (long long)steps * B * C;
     if (n <= 0) return;
-    hipLaunchKernelGGL(flow_mod_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, te, cemb, Y, steps, B, C);
+    hipLaunchKernelGGL(flow_mod_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, te, cemb, splits, bias, Y, steps, B, C);
 }
 
 }  // namespace ptts
