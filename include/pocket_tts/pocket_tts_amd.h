@@ -127,7 +127,8 @@ POCKET_TTS_API int ptts_audio_normalize(const float* in, int n, float* out);
 
 /* Benchmark support: HIP-event timing on the streams the engine launches on.  Both arrays hold 4 entries:
  * [0] LM frame step (kernel chain), [1] flow phase (adaLN GEMMs + fused head), [2] decoder chunk,
- * [3] the fused flow-head kernel alone; times_ms = totals, calls = number of launches of each. */
+ * [3] the flow head's launch chain alone (lsd_steps * (blocks + 1) launches per frame, counted in calls[3]);
+ * times_ms = totals, calls = number of launches of each. */
 POCKET_TTS_API int ptts_phase_timing(PocketTTSHandle handle, int enable);
 POCKET_TTS_API int ptts_phase_times(PocketTTSHandle handle, double* times_ms, long* calls);
 /* bytes[0..3] = GEMM weight bytes (compute precision) of the LM, the flow head, the decoder, the encoder */

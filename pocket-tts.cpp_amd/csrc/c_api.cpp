@@ -295,7 +295,7 @@ POCKET_TTS_API void* pocket_tts_stage_ids(PocketTTSHandle handle, int n, const l
 POCKET_TTS_API int pocket_tts_run_staged(PocketTTSHandle handle, void* staged, int* frames_out) {
     if (!handle || !staged || !frames_out) { set_error("Invalid parameters"); return -1; }
     return guarded("run_staged: ", [&] {
-        auto* b = static_cast<ptts::Batch*>(staged);
+        auto* b = static_cast<ptts::Job*>(staged);
         std::vector<int> frames;
         tts_of(handle)->engine().run_staged(*b, frames, nullptr);
         for (size_t i = 0; i < frames.size(); ++i) frames_out[i] = frames[i];
@@ -307,7 +307,7 @@ POCKET_TTS_API int pocket_tts_fetch_staged(PocketTTSHandle handle, void* staged,
                                            float* const* latents_out) {
     if (!handle || !staged || !frames) { set_error("Invalid parameters"); return -1; }
     return guarded("fetch_staged: ", [&] {
-        auto* b = static_cast<ptts::Batch*>(staged);
+        auto* b = static_cast<ptts::Job*>(staged);
         auto& e = tts_of(handle)->engine();
         std::vector<int> fr(frames, frames + b->B);
         for (int f : fr)

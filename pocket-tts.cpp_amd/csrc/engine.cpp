@@ -268,6 +268,7 @@ void Model::build_rope_tables(int lm_len, int mimi_len) {
 static constexpr int kDecChunk = 15;  // frames per decoder call, /root/reference/src/pocket_tts.cpp:461
 
 Batch::Batch(Engine& e, int B_) : B(B_) {
+    st = e.stream_; dec_st = e.dec_stream_; ready = e.latents_ready_;
     const Spec& s = e.spec();
     const EngineOptions& o = e.options();
     const int D = s.d_model, M = s.mimi_dim, L = s.latent, U = s.upsample;
@@ -328,6 +329,13 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     audio.alloc(static_cast<size_t>(B) * kDecChunk * s.frame_size() * 4);
     PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_eos), static_cast<size_t>(B) * 4));
     PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_x0), static_cast<size_t>(B) * L * 4));
+    PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_eos_all), static_cast<size_t>(o.max_frames) * B * 4, hipHostMallocMapped));
+    PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_flag), 64, hipHostMallocMapped));
+    *h_flag = 0;
+    step_dev.alloc(64);
+    partial.alloc(static_cast<size_t>(16) * B * D * 4);   // up to 16 K-slice slabs, sized once: the frame graph holds the pointer
+    for (auto& pair : tev)
+        for (auto& ev : pair) PTTS_HIP(hipEventCreate(&ev));
     reset(e.stream());
 }
 
@@ -347,8 +355,15 @@ void Batch::ensure_rows(size_t rows, int d, int ffn) {
 }
 
 Batch::~Batch() {
+    for (auto& ex : frame_exec)
+        if (ex) (void)hipGraphExecDestroy(ex);
+    for (auto& pair : tev)
+        for (auto& ev : pair)
+            if (ev) (void)hipEventDestroy(ev);
     if (h_eos) (void)hipHostFree(h_eos);
     if (h_x0) (void)hipHostFree(h_x0);
+    if (h_eos_all) (void)hipHostFree(h_eos_all);
+    if (h_flag) (void)hipHostFree(h_flag);
 }
 
 // Zero every recurrent state: the reference zero-initialises all state_* inputs (src/pocket_tts.cpp:133-186).
@@ -401,6 +416,24 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
     }
     PTTS_HIP(hipEventCreateWithFlags(&latents_ready_, hipEventDisableTiming));
     PTTS_HIP(hipEventCreateWithFlags(&dec_done_, hipEventDisableTiming));
+    lanes_ = opt_.lanes;
+    if (lanes_ <= 0) {
+        const char* e = std::getenv("POCKET_TTS_LANES");
+        lanes_ = e ? std::atoi(e) : 1;   // measured on MI355X: kernels of separate streams barely overlap at this launch size
+    }
+    lanes_ = std::max(1, std::min(lanes_, 8));
+    use_graph_ = std::getenv("POCKET_TTS_NO_GRAPH") == nullptr;
+    if (const char* e = std::getenv("POCKET_TTS_LANE_DECODER")) lane_shared_decoder_ = std::string(e) == "shared";
+    lane_streams_.push_back(stream_);
+    lane_events_.push_back(latents_ready_);
+    for (int i = 1; i < lanes_; ++i) {
+        hipStream_t ls;
+        hipEvent_t le;
+        PTTS_HIP(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
+        PTTS_HIP(hipEventCreateWithFlags(&le, hipEventDisableTiming));
+        lane_streams_.push_back(ls);
+        lane_events_.push_back(le);
+    }
     Pack pack(opt_.pack_path);
     model_ = std::make_unique<Model>(pack, opt_.precision);
     const Spec& s = model_->spec();
@@ -465,6 +498,7 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
             hd_.enc_c1_b[i] = m.f(q + "res.c1.b"); hd_.enc_c2_b[i] = m.f(q + "res.c2.b"); hd_.enc_down_b[i] = m.f(q + "down.b");
         }
     }
+    flow_head_prepare(s.flow_dim, model_->flow_wtype);
     flow_te_.alloc(te.size() * 4);
     PTTS_HIP(hipMemcpy(flow_te_.p, te.data(), te.size() * 4, hipMemcpyHostToDevice));
     PTTS_HIP(hipEventCreate(&ev_[0]));
@@ -475,9 +509,14 @@ Engine::~Engine() {
     (void)hipSetDevice(opt_.device);
     (void)hipStreamSynchronize(stream_);
     batch_pool_.clear();
-    for (auto& pe : pending_events_) { (void)hipEventDestroy(pe.second.first); (void)hipEventDestroy(pe.second.second); }
+    for (auto& pe : pending_events_) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     if (ev_[0]) (void)hipEventDestroy(ev_[0]);
     if (ev_[1]) (void)hipEventDestroy(ev_[1]);
+    for (size_t i = 1; i < lane_streams_.size(); ++i) {
+        (void)hipStreamSynchronize(lane_streams_[i]);
+        (void)hipStreamDestroy(lane_streams_[i]);
+        (void)hipEventDestroy(lane_events_[i]);
+    }
     if (latents_ready_) (void)hipEventDestroy(latents_ready_);
     if (dec_done_) (void)hipEventDestroy(dec_done_);
     if (dec_stream_) { (void)hipStreamSynchronize(dec_stream_); (void)hipStreamDestroy(dec_stream_); }
@@ -489,33 +528,41 @@ void Engine::enable_phase_timing(bool on) { timing_ = on; times_ = PhaseTimes();
 void Engine::phase_begin(int which, hipStream_t st) {
     if (!timing_) return;
     if (!st) st = stream_;
-    hipEvent_t a, b;
-    PTTS_HIP(hipEventCreate(&a));
-    PTTS_HIP(hipEventCreate(&b));
-    PTTS_HIP(hipEventRecord(a, st));
-    pending_events_.push_back({which, {a, b}});
+    PhaseEvent pe;
+    pe.which = which; pe.st = st;
+    PTTS_HIP(hipEventCreate(&pe.a));
+    PTTS_HIP(hipEventCreate(&pe.b));
+    PTTS_HIP(hipEventRecord(pe.a, st));
+    std::lock_guard<std::mutex> g(ev_mu_);
+    pending_events_.push_back(pe);
 }
 
 void Engine::phase_end(int which, hipStream_t st) {
     if (!timing_) return;
     if (!st) st = stream_;
+    std::lock_guard<std::mutex> g(ev_mu_);
     for (auto it = pending_events_.rbegin(); it != pending_events_.rend(); ++it)
-        if (it->first == which) { PTTS_HIP(hipEventRecord(it->second.second, st)); return; }
+        if (it->which == which && it->st == st && !it->closed) {
+            PTTS_HIP(hipEventRecord(it->b, st));
+            it->closed = true;
+            return;
+        }
 }
 
 Engine::PhaseTimes Engine::phase_times() {
-    PTTS_HIP(hipStreamSynchronize(stream_));
+    for (hipStream_t ls : lane_streams_) PTTS_HIP(hipStreamSynchronize(ls));
     PTTS_HIP(hipStreamSynchronize(dec_stream_));
+    std::lock_guard<std::mutex> g(ev_mu_);
     for (auto& pe : pending_events_) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) {
-            if (pe.first == 0) { times_.lm_ms += ms; times_.lm_calls++; }
-            else if (pe.first == 1) { times_.flow_ms += ms; times_.flow_calls++; }
-            else if (pe.first == 2) { times_.dec_ms += ms; times_.dec_calls++; }
+        if (pe.closed && hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+            if (pe.which == 0) { times_.lm_ms += ms; times_.lm_calls++; }
+            else if (pe.which == 1) { times_.flow_ms += ms; times_.flow_calls++; }
+            else if (pe.which == 2) { times_.dec_ms += ms; times_.dec_calls++; }
             else { times_.head_ms += ms; times_.head_calls++; }
         }
-        (void)hipEventDestroy(pe.second.first);
-        (void)hipEventDestroy(pe.second.second);
+        (void)hipEventDestroy(pe.a);
+        (void)hipEventDestroy(pe.b);
     }
     pending_events_.clear();
     return times_;
@@ -528,11 +575,17 @@ Batch* Engine::batch_new(int B) {
 void Engine::batch_free(Batch* b) { delete b; }
 void Engine::batch_reset(Batch* b) { b->reset(stream_); }
 
-Batch* Engine::acquire_batch(int B) {
-    auto it = batch_pool_.find(B);
-    if (it == batch_pool_.end()) it = batch_pool_.emplace(B, std::make_unique<Batch>(*this, B)).first;
-    else it->second->reset(stream_);
-    return it->second.get();
+Batch* Engine::acquire_batch(int B, int lane) {
+    auto key = std::make_pair(B, lane);
+    auto it = batch_pool_.find(key);
+    const bool fresh = it == batch_pool_.end();
+    if (fresh) it = batch_pool_.emplace(key, std::make_unique<Batch>(*this, B)).first;
+    Batch* b = it->second.get();
+    b->st = lane_streams_[lane];
+    b->ready = lane_events_[lane];
+    b->dec_st = dec_stream_;
+    if (!fresh) b->reset(b->st);
+    return b;
 }
 
 // One pre-norm transformer stack over M = nb * rpb new rows X[M][d] (in place), appending to the
@@ -594,9 +647,9 @@ void Engine::lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* 
     const auto& layers = hd_.lm;
     const long long layer_stride = static_cast<long long>(b.B) * b.lm_cap * s.d_model;
     transformer(layers, b.lm_k.f(), b.lm_v.f(), layer_stride, b.lm_cap, b.lm_pos.as<int>() + slot0, slot0, nb, rpb, X, s.d_model,
-                s.lm_heads, s.lm_ffn, s.lm_eps, 0, model_->lm_cos, model_->lm_sin, model_->lm_tab_len, b.scratch(), nullptr, 0, 0, stream_, true);
-    if (adv_dev) launch_advance_pos_vec(b.lm_pos.as<int>() + slot0, adv_dev, nb, stream_);
-    else launch_advance_pos(b.lm_pos.as<int>() + slot0, nb, rpb, stream_);
+                s.lm_heads, s.lm_ffn, s.lm_eps, 0, model_->lm_cos, model_->lm_sin, model_->lm_tab_len, b.scratch(), nullptr, 0, 0, b.st, true);
+    if (adv_dev) launch_advance_pos_vec(b.lm_pos.as<int>() + slot0, adv_dev, nb, b.st);
+    else launch_advance_pos(b.lm_pos.as<int>() + slot0, nb, rpb, b.st);
     for (int i = 0; i < nb; ++i) b.lm_pos_host[slot0 + i] += adv_host ? adv_host[i] : rpb;
 }
 
@@ -617,48 +670,44 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
     const Spec& s = spec();
     const int B = b.B, D = s.d_model, F = s.lm_ffn;
     const int wt = model_->flow_wtype, kstep = wt == W_BF16 ? 32 : 16;
-    for (int i = 0; i < B; ++i)
-        if (b.lm_pos_host[i] + 1 > b.lm_cap) throw std::runtime_error("LM context exceeds the KV-cache capacity (voice + text + frames too long)");
-    phase_begin(0);
-    launch_prep_latent(seq_dev, b.seq_in.f(), B, s.latent, 0, hd_.bos, nullptr, stream_);
+    launch_prep_latent(seq_dev, b.seq_in.f(), B, s.latent, 0, hd_.bos, nullptr, b.st);
     const DevWeight& win = hd_.lm_in;
     GemmArgs g;
     g.A = b.seq_in.f(); g.lda = s.latent; g.W = win.p; g.wtype = win.wtype; g.C = b.x.f(); g.ldc = D;
     g.M = B; g.N = D; g.K = s.latent; g.split_a = 1;
-    launch_gemm(g, stream_);
+    launch_gemm(g, b.st);
     const int s_out = pick_splits(D, kstep), s_ff2 = pick_splits(F, kstep);
-    const size_t pneed = static_cast<size_t>(std::max(s_out, s_ff2)) * B * D * 4;
-    if (b.partial.bytes < pneed) b.partial.alloc(pneed);
+    if (b.partial.bytes < static_cast<size_t>(std::max(s_out, s_ff2)) * B * D * 4) throw std::runtime_error("split-K slab buffer too small");
     AddNormArgs an;
     an.X = b.x.f(); an.ldx = D; an.M = B; an.D = D; an.eps = s.lm_eps;
     an.g = hd_.lm[0].ln1g; an.b = hd_.lm[0].ln1b; an.H = b.h.f();
-    launch_add_norm(an, stream_);
+    launch_add_norm(an, b.st);
     const long long layer_stride = static_cast<long long>(B) * b.lm_cap * D;
     for (int l = 0; l < s.lm_layers; ++l) {
         const TfLayer& w = hd_.lm[l];
         const Model::PackedLayer& pw = model_->lm_packed[l];
         SkinnyArgs q;
         q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.wtype = wt; q.M = B; q.N = 3 * D; q.K = D; q.C = b.qkv.f(); q.ldc = 3 * D;
-        launch_skinny_gemm(q, stream_);
+        launch_skinny_gemm(q, b.st);
         AttnDecodeArgs at;
         at.qkv = b.qkv.f(); at.kcache = b.lm_k.f() + l * layer_stride; at.vcache = b.lm_v.f() + l * layer_stride;
         at.pos = b.lm_pos.as<int>(); at.M = B; at.d = D; at.heads = s.lm_heads; at.cap = b.lm_cap; at.window = 0;
         at.cos_tab = model_->lm_cos; at.sin_tab = model_->lm_sin; at.tab_len = model_->lm_tab_len;
         at.out = b.att.f();
-        launch_attn_decode(at, stream_);
+        launch_attn_decode(at, b.st);
         SkinnyArgs o;
         o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.wtype = wt; o.M = B; o.N = D; o.K = D; o.splits = s_out; o.P = b.partial.f();
-        launch_skinny_gemm(o, stream_);
+        launch_skinny_gemm(o, b.st);
         AddNormArgs a1 = an;
         a1.P = b.partial.f(); a1.splits = s_out; a1.colscale = w.ls1; a1.g = w.ln2g; a1.b = w.ln2b;
-        launch_add_norm(a1, stream_);
+        launch_add_norm(a1, b.st);
         SkinnyArgs f1;
         f1.A = b.h.f(); f1.lda = D; f1.Wp = pw.ff1; f1.wtype = wt; f1.M = B; f1.N = F; f1.K = D; f1.act = ACT_GELU;
         f1.C = b.ff.f(); f1.ldc = F;
-        launch_skinny_gemm(f1, stream_);
+        launch_skinny_gemm(f1, b.st);
         SkinnyArgs f2;
         f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.wtype = wt; f2.M = B; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.partial.f();
-        launch_skinny_gemm(f2, stream_);
+        launch_skinny_gemm(f2, b.st);
         AddNormArgs a2 = an;
         a2.P = b.partial.f(); a2.splits = s_ff2; a2.colscale = w.ls2;
         if (l + 1 < s.lm_layers) {
@@ -668,38 +717,42 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
             a2.dot_w = hd_.eos_w; a2.dot_b = hd_.eos_b; a2.dot_out = eos_dev;
             a2.pos = b.lm_pos.as<int>(); a2.pos_delta = 1;
         }
-        launch_add_norm(a2, stream_);
+        launch_add_norm(a2, b.st);
     }
-    for (int i = 0; i < B; ++i) b.lm_pos_host[i] += 1;
-    phase_end(0);
+}
+
+// Host mirror of the positions one decode step consumes; call once per step actually run.
+void Engine::lm_bookkeeping(Batch& b) {
+    for (int i = 0; i < b.B; ++i) {
+        if (b.lm_pos_host[i] + 1 > b.lm_cap) throw std::runtime_error("LM context exceeds the KV-cache capacity (voice + text + frames too long)");
+        b.lm_pos_host[i] += 1;
+    }
 }
 
 // lsd_steps Euler iterations for B rows: 3 small launches for the adaLN vectors, then the head's per-block chain.
-void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B) {
+void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B,
+                      const int* x0_step, long long x0_step_stride, hipEvent_t probe_a, hipEvent_t probe_b) {
     const Spec& s = spec();
     const int C = s.flow_dim, N = opt_.lsd_steps;
-    phase_begin(1);
     // conditioning embedding as K-slice slabs (skinny product), summed inside the next kernel
     const int wt = model_->flow_wtype;
     const int cs = pick_splits(s.d_model, wt == W_BF16 ? 32 : 16);
     SkinnyArgs g;
     g.A = cond_dev; g.lda = s.d_model; g.Wp = model_->flow_cond_packed; g.wtype = wt; g.M = B; g.N = C; g.K = s.d_model;
     g.splits = cs; g.P = b.cemb.f();
-    launch_skinny_gemm(g, stream_);
-    launch_flow_mod_input(flow_te_.f(), b.cemb.f(), cs, hd_.flow_cond_b, b.ymod.f(), N, B, C, stream_);
+    launch_skinny_gemm(g, b.st);
+    launch_flow_mod_input(flow_te_.f(), b.cemb.f(), cs, hd_.flow_cond_b, b.ymod.f(), N, B, C, b.st);
     GemmArgs m;
     m.A = b.ymod.f(); m.lda = C; m.W = model_->ada_all.p; m.wtype = model_->ada_all.wtype; m.C = b.mods.f(); m.ldc = model_->mod_width;
     m.bias = model_->ada_all_b; m.M = N * B; m.N = model_->mod_width; m.K = C; m.split_a = 1;
-    launch_gemm(m, stream_);
+    launch_gemm(m, b.st);
     FlowHeadArgs fa;
     fa.x0 = x0_dev; fa.x0_stride = x0_stride; fa.x_out = x_out_dev; fa.mods = b.mods.f(); fa.B = B; fa.L = s.latent; fa.C = C; fa.blocks = s.flow_blocks;
     fa.steps = N; fa.mod_width = model_->mod_width;
     fa.w_in = model_->flow_in_packed; fa.b_in = hd_.flow_in_b; fa.w_out = model_->flow_out_packed; fa.b_out = hd_.flow_out_b;
     fa.host_tabs = &model_->flow_tabs; fa.workspace = b.flow_ws.f(); fa.wtype = model_->flow_wtype; fa.eps = s.flow_eps;
-    phase_begin(3);
-    launch_flow_head(fa, stream_);
-    phase_end(3);
-    phase_end(1);
+    fa.x0_step = x0_step; fa.x0_step_stride = x0_step_stride; fa.probe_a = probe_a; fa.probe_b = probe_b;
+    launch_flow_head(fa, b.st);
 }
 
 // latent rows (batched mapping: utterance b at lat_dev + b*lat_bs, n rows of `latent` floats)

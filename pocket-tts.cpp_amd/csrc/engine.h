@@ -77,6 +77,7 @@ struct EngineOptions {
     int max_text_tokens = 512;
     uint64_t seed = 0;         // 0: seed from std::random_device like the reference (src/pocket_tts.cpp:72)
     bool has_seed = false;
+    int lanes = 0;             // concurrent sub-batches per staged batch (0: POCKET_TTS_LANES or the built-in default)
 };
 
 struct Utterance {
@@ -101,6 +102,15 @@ using ChunkCallback = std::function<void(const float*, int, bool)>;
 
 class Batch;
 
+// A staged batch: the utterances cut into contiguous parts, each part a lock-step Batch that runs on its own
+// stream ("lane").  The frame loop is a chain of small dependent launches that leaves most of the chip idle,
+// so several parts in flight at once multiply throughput at nearly unchanged per-frame latency.
+struct Job {
+    std::vector<Batch*> parts;
+    std::vector<int> first;   // index of each part's first utterance
+    int B = 0;
+};
+
 class Engine {
 public:
     explicit Engine(const EngineOptions& opt);
@@ -116,9 +126,10 @@ public:
     // The same in three parts, so a benchmark can time the device-resident middle on its own:
     //   stage (host -> HBM), run_staged (prefill + frame loop + decode, audio left in HBM), fetch_staged (HBM -> host).
     // Hold call_mutex() across the three when other threads may use the engine.
-    Batch* stage(const std::vector<Utterance>& utts);
-    void run_staged(Batch& b, std::vector<int>& frames, std::vector<std::vector<float>>* eos_log);
-    void fetch_staged(Batch& b, const std::vector<int>& frames, std::vector<UtteranceResult>& out, bool want_latents);
+    // The Job belongs to the engine and stays valid until the next stage() call.
+    Job* stage(const std::vector<Utterance>& utts);
+    void run_staged(Job& job, std::vector<int>& frames, std::vector<std::vector<float>>* eos_log);
+    void fetch_staged(Job& job, const std::vector<int>& frames, std::vector<UtteranceResult>& out, bool want_latents);
     std::recursive_mutex& call_mutex() { return call_mu_; }
     // Streaming, single utterance: /root/reference/src/pocket_tts.cpp:686-979.  Returns total samples.
     // cancel_flag (may be null) is polled once per frame when poll_cancel is set, and always suppresses the
@@ -154,13 +165,20 @@ private:
                      const int* pos_dev, int slot0, int nb, int rpb, float* X, int d, int heads, int ffn, float eps,
                      int window, const float* cos_tab, const float* sin_tab, int tab_len, const TfScratch& scratch,
                      float* last_out, long long last_bs, int last_ld, hipStream_t st, bool split_a = false);
+    void stage_part(Batch& b, const Utterance* utts, int n);
+    // One frame of the autoregressive loop for a staged batch, free of host-side frame state (replayable as a graph):
+    // LM step -> EOS logits to the host -> flow head from the start points of frame *step -> latent filed under *step.
+    void frame_body(Batch& b, int parity);
+    void ensure_frame_graph(Batch& b);
+    void lm_bookkeeping(Batch& b);
     void lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* adv_dev = nullptr, const int* adv_host = nullptr);
     void lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev);
-    void flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B);
+    void flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B,
+                  const int* x0_step = nullptr, long long x0_step_stride = 0, hipEvent_t probe_a = nullptr, hipEvent_t probe_b = nullptr);
     void mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs, hipStream_t st);
     void prefill_utterance(Batch& b, int slot, const Utterance& u);
     void fill_noise(std::vector<std::mt19937>& rngs, const std::vector<Utterance>& utts, int step, float* host_x0);
-    Batch* acquire_batch(int B);
+    Batch* acquire_batch(int B, int lane = 0);
     void phase_begin(int which, hipStream_t st = nullptr);
     void phase_end(int which, hipStream_t st = nullptr);
 
@@ -183,11 +201,19 @@ private:
     std::recursive_mutex call_mu_;
     std::mt19937 rng_;
     DevBuf flow_te_;  // [lsd_steps][C] averaged time embeddings of the fixed (s_j, t_j) grid
-    std::map<int, std::unique_ptr<Batch>> batch_pool_;
+    std::map<std::pair<int, int>, std::unique_ptr<Batch>> batch_pool_;   // (rows, lane)
+    std::vector<hipStream_t> lane_streams_;     // lane 0 = stream_
+    std::vector<hipEvent_t> lane_events_;
+    bool lane_shared_decoder_ = false;          // parts > 1: decoder chunks on dec_stream_ instead of the lane's own stream
+    int lanes_ = 1;
+    bool use_graph_ = true;                     // replay each frame as one hipGraph (POCKET_TTS_NO_GRAPH=1: eager launches)
+    Job job_;
+    std::mutex ev_mu_;
     bool timing_ = false;
     hipEvent_t ev_[2] = {nullptr, nullptr};
     PhaseTimes times_;
-    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events_;
+    struct PhaseEvent { int which = 0; hipStream_t st = nullptr; hipEvent_t a = nullptr, b = nullptr; bool closed = false; };
+    std::vector<PhaseEvent> pending_events_;
 };
 
 // Recurrent state and scratch of B lock-step utterances on one GPU.
@@ -197,6 +223,9 @@ public:
     void reset(hipStream_t s);
 
     int B;
+    hipStream_t st = nullptr;       // frame-loop stream of this batch
+    hipStream_t dec_st = nullptr;   // decoder stream (may equal st)
+    hipEvent_t ready = nullptr;     // latents of a chunk are complete (st -> dec_st)
     int lm_cap;       // KV capacity per slot (positions)
     int dec_cap;      // ring capacity of the decoder transformer cache
     int max_rows;     // scratch rows for transformer passes
@@ -233,6 +262,15 @@ public:
     // pinned host staging
     float* h_eos = nullptr;
     float* h_x0 = nullptr;
+    // frame loop state that lives on the device / in mapped host memory (see Engine::frame_body)
+    DevBuf step_dev;                 // int: index of the frame being generated
+    float* h_eos_all = nullptr;      // [max_frames][B] EOS logits, written by the GPU
+    int* h_flag = nullptr;           // number of frames whose EOS logits have arrived
+    const float* x0_src = nullptr;   // start points of the staged batch and their strides
+    long long x0_stride = 0, x0_step_stride = 0;
+    hipGraphExec_t frame_exec[2] = {nullptr, nullptr};   // one per frame parity (each has its own timing events)
+    const float* graph_x0 = nullptr; long long graph_x0_stride = -1; bool graph_timed = false;
+    hipEvent_t tev[2][8] = {};       // lm begin/end, flow begin, probe begin/end, flow end, and an empty back-to-back pair
     ~Batch();
 };
 

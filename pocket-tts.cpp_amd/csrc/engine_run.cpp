@@ -64,27 +64,45 @@ void Engine::fill_noise(std::vector<std::mt19937>& rngs, const std::vector<Utter
 }
 
 // Upload everything a batch needs (conditioning rows, token ids, start points) so that run_staged()
-// touches host memory only for the per-step EOS logits.
-Batch* Engine::stage(const std::vector<Utterance>& utts) {
+// touches host memory only for the per-step EOS logits.  The batch is cut into up to `lanes` contiguous parts
+// of at least 16 utterances (one MFMA row group) each.
+Job* Engine::stage(const std::vector<Utterance>& utts) {
     std::lock_guard<std::mutex> guard(mu_);
     PTTS_HIP(hipSetDevice(opt_.device));
-    const Spec& s = spec();
-    const int B = static_cast<int>(utts.size()), L = s.latent, D = s.d_model;
+    const int B = static_cast<int>(utts.size());
     if (B == 0) throw std::runtime_error("empty batch");
-    Batch& b = *acquire_batch(B);
-    int vmax = 1;
     for (auto& u : utts) {
         if (u.token_ids.empty()) throw std::runtime_error("Text cannot be empty");
         if (static_cast<int>(u.token_ids.size()) > opt_.max_text_tokens) throw std::runtime_error("text has more tokens than the engine was sized for");
-        vmax = std::max(vmax, u.voice_frames);
     }
+    int parts = std::min(lanes_, std::max(1, B / 16));
+    const int per = ((B + parts - 1) / parts + 15) / 16 * 16;   // whole row groups per part
+    parts = (B + per - 1) / per;
+    job_.parts.clear(); job_.first.clear(); job_.B = B;
+    for (int p = 0; p < parts; ++p) {
+        const int first = p * per, n = std::min(per, B - first);
+        Batch* b = acquire_batch(n, p);
+        if (parts > 1 && !lane_shared_decoder_) b->dec_st = b->st;   // decoder chunks in line: other lanes fill the gap
+        stage_part(*b, utts.data() + first, n);
+        job_.parts.push_back(b);
+        job_.first.push_back(first);
+    }
+    for (Batch* b : job_.parts) PTTS_HIP(hipStreamSynchronize(b->st));
+    return &job_;
+}
+
+void Engine::stage_part(Batch& b, const Utterance* utts, int B) {
+    const Spec& s = spec();
+    const int L = s.latent, D = s.d_model;
+    int vmax = 1;
+    for (int i = 0; i < B; ++i) vmax = std::max(vmax, utts[i].voice_frames);
     b.st_vmax = vmax;
     if (b.voice_stage.bytes < static_cast<size_t>(B) * vmax * D * 4) b.voice_stage.alloc(static_cast<size_t>(B) * vmax * D * 4);
     if (b.ids_stage.bytes < static_cast<size_t>(B) * opt_.max_text_tokens * 8) b.ids_stage.alloc(static_cast<size_t>(B) * opt_.max_text_tokens * 8);
     b.st_voice_frames.assign(B, 0);
     b.st_ntok.assign(B, 0);
     bool any_noise = opt_.temperature > 0;
-    for (auto& u : utts) any_noise = any_noise || u.noise;
+    for (int i = 0; i < B; ++i) any_noise = any_noise || utts[i].noise;
     b.st_has_noise = any_noise;
     for (int i = 0; i < B; ++i) {
         const Utterance& u = utts[i];
@@ -92,9 +110,9 @@ Batch* Engine::stage(const std::vector<Utterance>& utts) {
         b.st_ntok[i] = static_cast<int>(u.token_ids.size());
         if (u.voice_frames)
             PTTS_HIP(hipMemcpyAsync(b.voice_stage.f() + static_cast<size_t>(i) * vmax * D, u.voice, static_cast<size_t>(u.voice_frames) * D * 4,
-                                    hipMemcpyHostToDevice, stream_));
+                                    hipMemcpyHostToDevice, b.st));
         PTTS_HIP(hipMemcpyAsync(b.ids_stage.as<long long>() + static_cast<size_t>(i) * opt_.max_text_tokens, u.token_ids.data(),
-                                u.token_ids.size() * 8, hipMemcpyHostToDevice, stream_));
+                                u.token_ids.size() * 8, hipMemcpyHostToDevice, b.st));
     }
     if (any_noise) {
         // Start points for every frame: explicit ones, else N(0, sqrt(T)) from a fresh distribution object per
@@ -114,125 +132,232 @@ Batch* Engine::stage(const std::vector<Utterance>& utts) {
                 }
             }
         }
-        PTTS_HIP(hipMemcpyAsync(b.noise_all.p, host.data(), host.size() * 4, hipMemcpyHostToDevice, stream_));
-        PTTS_HIP(hipStreamSynchronize(stream_));
+        PTTS_HIP(hipMemcpyAsync(b.noise_all.p, host.data(), host.size() * 4, hipMemcpyHostToDevice, b.st));
+        PTTS_HIP(hipStreamSynchronize(b.st));
     }
     const size_t audio_need = static_cast<size_t>(B) * opt_.max_frames * s.frame_size() * 4;
     if (b.audio_all.bytes < audio_need) b.audio_all.alloc(audio_need);
-    PTTS_HIP(hipStreamSynchronize(stream_));
-    return &b;
+    PTTS_HIP(hipStreamSynchronize(b.st));
 }
 
-// Prefill, frame loop and chunked decode for a staged batch; audio stays in HBM (b.audio_all).
-// Offline schedule of /root/reference/src/pocket_tts.cpp:548-657 applied to every utterance.
-void Engine::run_staged(Batch& b, std::vector<int>& frames, std::vector<std::vector<float>>* eos_log) {
+// One frame, free of host-side frame state.  With timing on, the events of this parity are recorded around the
+// phases (as graph nodes when the body is being captured).
+void Engine::frame_body(Batch& b, int parity) {
+    hipStream_t st = b.st;
+    hipEvent_t* ev = timing_ ? b.tev[parity] : nullptr;
+    if (ev) PTTS_HIP(hipEventRecord(ev[0], st));
+    lm_step_dev(b, b.xcur.f(), b.cond.f(), b.eos.f());                                      // :591
+    if (ev) PTTS_HIP(hipEventRecord(ev[1], st));
+    launch_publish_eos(b.eos.f(), b.B, b.step_dev.as<int>(), b.h_eos_all, b.h_flag, st);
+    if (ev) PTTS_HIP(hipEventRecord(ev[2], st));
+    flow_dev(b, b.cond.f(), b.x0_src, b.x0_stride, b.xcur.f(), b.B, b.step_dev.as<int>(), b.x0_step_stride,  // :606-622
+             ev ? ev[3] : nullptr, ev ? ev[4] : nullptr);
+    if (ev) {
+        PTTS_HIP(hipEventRecord(ev[5], st));
+        PTTS_HIP(hipEventRecord(ev[6], st));   // nothing between these two: what a bracketing pair costs by itself
+        PTTS_HIP(hipEventRecord(ev[7], st));
+    }
+    launch_store_latent(b.xcur.f(), b.latents.f(), b.B, spec().latent, opt_.max_frames, b.step_dev.as<int>(), st);
+}
+
+// (Re)captures the frame graphs of a batch when its start-point source or the timing mode changed.
+void Engine::ensure_frame_graph(Batch& b) {
+    if (b.frame_exec[0] && b.graph_x0 == b.x0_src && b.graph_x0_stride == b.x0_stride && b.graph_timed == timing_) return;
+    for (auto& ex : b.frame_exec)
+        if (ex) { PTTS_HIP(hipGraphExecDestroy(ex)); ex = nullptr; }
+    for (int parity = 0; parity < 2; ++parity) {
+        hipGraph_t g = nullptr;
+        PTTS_HIP(hipStreamBeginCapture(b.st, hipStreamCaptureModeThreadLocal));
+        try {
+            frame_body(b, parity);
+        } catch (...) {
+            (void)hipStreamEndCapture(b.st, &g);
+            if (g) (void)hipGraphDestroy(g);
+            throw;
+        }
+        PTTS_HIP(hipStreamEndCapture(b.st, &g));
+        PTTS_HIP(hipGraphInstantiate(&b.frame_exec[parity], g, nullptr, nullptr, 0));
+        PTTS_HIP(hipGraphDestroy(g));
+    }
+    b.graph_x0 = b.x0_src; b.graph_x0_stride = b.x0_stride; b.graph_timed = timing_;
+}
+
+// Prefill, frame loop and chunked decode for a staged batch; audio stays in HBM (audio_all of every part).
+// Offline schedule of /root/reference/src/pocket_tts.cpp:548-657 applied to every utterance.  All parts are
+// driven from this one thread: a frame is one graph launch, the EOS logits of step k reach the host while the
+// flow head of step k is still running, and step k+1 is enqueued behind it at once, so neither the host nor
+// the other parts ever wait for a whole frame.
+void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std::vector<float>>* eos_log) {
     std::lock_guard<std::mutex> guard(mu_);
     PTTS_HIP(hipSetDevice(opt_.device));
     const Spec& s = spec();
-    const int B = b.B, L = s.latent, D = s.d_model, fs = s.frame_size();
-    b.reset(stream_);
-    // Prefill.  The reference feeds the voice rows and then the text rows of an utterance as two causal passes
-    // (:572, :575); one causal pass over [voice; text] writes the same KV cache.  All utterances go through
-    // together, padded to the longest; padding rows land beyond each utterance's real length in its cache,
-    // are never attended to by real rows, and are overwritten by the frames that follow.
-    {
+    const int L = s.latent, D = s.d_model, fs = s.frame_size();
+    frames_out.assign(job.B, 0);
+    if (eos_log) eos_log->assign(job.B, std::vector<float>());
+
+    struct PartRun {
+        Batch* b; int first; std::vector<int> len, eos_step; std::vector<char> done;
+        int n_done = 0, decoded = 0, step = 0, executed = 0, timed = 0; bool launched = false, finished = false;
+    };
+    std::vector<PartRun> runs(job.parts.size());
+    for (size_t p = 0; p < runs.size(); ++p) {
+        PartRun& r = runs[p];
+        Batch& b = *job.parts[p];
+        r.b = &b; r.first = job.first[p];
+        const int B = b.B;
+        hipStream_t st = b.st;
+        b.reset(st);
+        PTTS_HIP(hipMemsetAsync(b.step_dev.p, 0, 4, st));
+        *b.h_flag = 0;
+        // Prefill.  The reference feeds the voice rows and then the text rows of an utterance as two causal passes
+        // (:572, :575); one causal pass over [voice; text] writes the same KV cache.  All utterances of a part go
+        // through together, padded to the longest; padding rows land beyond each utterance's real length in its
+        // cache, are never attended to by real rows, and are overwritten by the frames that follow.
         int rpb = 1;
-        std::vector<int> len(B);
-        for (int i = 0; i < B; ++i) { len[i] = b.st_voice_frames[i] + b.st_ntok[i]; rpb = std::max(rpb, len[i]); }
-        PTTS_HIP(hipMemcpyAsync(b.st_nv.p, b.st_voice_frames.data(), static_cast<size_t>(B) * 4, hipMemcpyHostToDevice, stream_));
-        PTTS_HIP(hipMemcpyAsync(b.st_nt.p, b.st_ntok.data(), static_cast<size_t>(B) * 4, hipMemcpyHostToDevice, stream_));
-        PTTS_HIP(hipMemcpyAsync(b.st_len.p, len.data(), static_cast<size_t>(B) * 4, hipMemcpyHostToDevice, stream_));
-        PTTS_HIP(hipStreamSynchronize(stream_));  // len[] is a local
+        r.len.resize(B);
+        for (int i = 0; i < B; ++i) { r.len[i] = b.st_voice_frames[i] + b.st_ntok[i]; rpb = std::max(rpb, r.len[i]); }
+        PTTS_HIP(hipMemcpyAsync(b.st_nv.p, b.st_voice_frames.data(), static_cast<size_t>(B) * 4, hipMemcpyHostToDevice, st));
+        PTTS_HIP(hipMemcpyAsync(b.st_nt.p, b.st_ntok.data(), static_cast<size_t>(B) * 4, hipMemcpyHostToDevice, st));
+        PTTS_HIP(hipMemcpyAsync(b.st_len.p, r.len.data(), static_cast<size_t>(B) * 4, hipMemcpyHostToDevice, st));
         b.ensure_rows(static_cast<size_t>(B) * rpb, D, s.lm_ffn);
         launch_assemble_prefill(b.voice_stage.f(), static_cast<long long>(b.st_vmax) * D, b.ids_stage.as<long long>(), opt_.max_text_tokens,
-                                b.st_nv.as<int>(), b.st_nt.as<int>(), hd_.text_embed, s.vocab + 1, D, rpb, B, b.x.f(), stream_);
-        lm_rows(b, 0, B, rpb, b.x.f(), b.st_len.as<int>(), len.data());
+                                b.st_nv.as<int>(), b.st_nt.as<int>(), hd_.text_embed, s.vocab + 1, D, rpb, B, b.x.f(), st);
+        lm_rows(b, 0, B, rpb, b.x.f(), b.st_len.as<int>(), r.len.data());
+        // BOS marker: NaN latent (:579)
+        for (int i = 0; i < B * L; ++i) b.h_x0[i] = std::numeric_limits<float>::quiet_NaN();
+        PTTS_HIP(hipMemcpyAsync(b.xcur.p, b.h_x0, static_cast<size_t>(B) * L * 4, hipMemcpyHostToDevice, st));
+        b.x0_src = b.st_has_noise ? b.noise_all.f() : b.x0.f();
+        b.x0_stride = b.st_has_noise ? static_cast<long long>(opt_.max_frames) * L : L;
+        b.x0_step_stride = b.st_has_noise ? L : 0;
+        r.eos_step.assign(B, -1);
+        r.done.assign(B, 0);
     }
-    // BOS marker: NaN latent (:579)
-    for (int i = 0; i < B * L; ++i) b.h_x0[i] = std::numeric_limits<float>::quiet_NaN();
-    PTTS_HIP(hipMemcpyAsync(b.xcur.p, b.h_x0, static_cast<size_t>(B) * L * 4, hipMemcpyHostToDevice, stream_));
+    // Events recorded by graph nodes cannot be read back with hipEventElapsedTime on this runtime, so a timed run
+    // launches the same frame body eagerly.
+    const bool graph = use_graph_ && !timing_;
+    if (graph)
+        for (auto& r : runs) {
+            const std::vector<int> keep = r.b->lm_pos_host;
+            ensure_frame_graph(*r.b);
+            r.b->lm_pos_host = keep;
+        }
 
-    frames.assign(B, 0);
-    if (eos_log) eos_log->assign(B, std::vector<float>());
-    std::vector<int> eos_step(B, -1);
-    std::vector<char> done(B, 0);
-    int n_done = 0, decoded = 0;
-    for (int step = 0; step < opt_.max_frames; ++step) {
-        lm_step_dev(b, b.xcur.f(), b.cond.f(), b.eos.f());                                  // :591
-        PTTS_HIP(hipMemcpyAsync(b.h_eos, b.eos.p, static_cast<size_t>(B) * 4, hipMemcpyDeviceToHost, stream_));
-        PTTS_HIP(hipStreamSynchronize(stream_));
-        for (int i = 0; i < B; ++i) {
-            if (done[i]) continue;
-            const float e = b.h_eos[i];
-            if (eos_log) (*eos_log)[i].push_back(e);
-            if (e > kEosThreshold && eos_step[i] < 0) eos_step[i] = step;                   // :596
-            if (eos_step[i] >= 0 && step >= eos_step[i] + opt_.frames_after_eos) { done[i] = 1; ++n_done; }  // :601
+    auto decode_chunk = [&](PartRun& r, int f0, int n) {
+        Batch& b = *r.b;
+        if (b.dec_st != b.st) {
+            PTTS_HIP(hipEventRecord(b.ready, b.st));
+            PTTS_HIP(hipStreamWaitEvent(b.dec_st, b.ready, 0));
         }
-        if (n_done == B) break;
-        const float* x0 = b.st_has_noise ? b.noise_all.f() + static_cast<size_t>(step) * L : b.x0.f();
-        const long long x0_stride = b.st_has_noise ? static_cast<long long>(opt_.max_frames) * L : L;
-        flow_dev(b, b.cond.f(), x0, x0_stride, b.xcur.f(), B);                              // :606-622
-        PTTS_HIP(hipMemcpy2DAsync(b.latents.f() + static_cast<size_t>(step) * L, static_cast<size_t>(opt_.max_frames) * L * 4, b.xcur.p,
-                                  static_cast<size_t>(L) * 4, static_cast<size_t>(L) * 4, B, hipMemcpyDeviceToDevice, stream_));
-        for (int i = 0; i < B; ++i)
-            if (!done[i]) frames[i]++;
-        // Every full 15-frame chunk goes to the decoder stream as soon as its latents exist: the decoder
-        // never feeds back into the frame loop, so it runs beside the following frames (the reference decodes
-        // after the loop, :640; the chunk boundaries and the carried state are the same).
-        if ((step + 1) % kDecChunk == 0) {
-            PTTS_HIP(hipEventRecord(latents_ready_, stream_));
-            PTTS_HIP(hipStreamWaitEvent(dec_stream_, latents_ready_, 0));
-            const int f0 = step + 1 - kDecChunk;
-            mimi_decode_dev(b, b.latents.f() + static_cast<size_t>(f0) * L, static_cast<long long>(opt_.max_frames) * L, kDecChunk,
-                            b.audio_all.f() + static_cast<size_t>(f0) * fs, static_cast<long long>(opt_.max_frames) * fs, dec_stream_);
-            decoded = step + 1;
-        }
-    }
-    int fmax = 0;
-    for (int i = 0; i < B; ++i) fmax = std::max(fmax, frames[i]);
-    // remaining frames (:454-546): chunks of <= 15 with the same carried state
-    PTTS_HIP(hipEventRecord(latents_ready_, stream_));
-    PTTS_HIP(hipStreamWaitEvent(dec_stream_, latents_ready_, 0));
-    for (int f0 = decoded; f0 < fmax; f0 += kDecChunk) {
-        const int n = std::min(kDecChunk, fmax - f0);
         mimi_decode_dev(b, b.latents.f() + static_cast<size_t>(f0) * L, static_cast<long long>(opt_.max_frames) * L, n,
-                        b.audio_all.f() + static_cast<size_t>(f0) * fs, static_cast<long long>(opt_.max_frames) * fs, dec_stream_);
+                        b.audio_all.f() + static_cast<size_t>(f0) * fs, static_cast<long long>(opt_.max_frames) * fs, b.dec_st);
+    };
+    auto collect_timing = [&](Batch& b, int parity) {
+        float lm = 0.f, fl = 0.f, hd = 0.f;
+        if (hipEventElapsedTime(&lm, b.tev[parity][0], b.tev[parity][1]) != hipSuccess) return;
+        if (hipEventElapsedTime(&fl, b.tev[parity][2], b.tev[parity][5]) != hipSuccess) return;
+        if (hipEventElapsedTime(&hd, b.tev[parity][3], b.tev[parity][4]) != hipSuccess) return;
+        float empty = 0.f;
+        if (hipEventElapsedTime(&empty, b.tev[parity][6], b.tev[parity][7]) != hipSuccess) return;
+        hd = std::max(hd - empty, 0.f);   // take the bracketing pair's own cost out
+        std::lock_guard<std::mutex> g(ev_mu_);
+        times_.lm_ms += lm; times_.lm_calls++;
+        times_.flow_ms += fl; times_.flow_calls++;
+        times_.head_ms += hd; times_.head_calls += opt_.lsd_steps * (spec().flow_blocks + 1);
+    };
+
+    size_t n_finished = 0;
+    while (n_finished < runs.size()) {
+        for (auto& r : runs) {
+            if (r.finished || r.launched) continue;
+            Batch& b = *r.b;
+            lm_bookkeeping(b);
+            if (graph) PTTS_HIP(hipGraphLaunch(b.frame_exec[r.step & 1], b.st));
+            else frame_body(b, r.step & 1);
+            r.launched = true;
+        }
+        for (auto& r : runs) {
+            if (r.finished || !r.launched) continue;
+            Batch& b = *r.b;
+            if (__atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < r.step + 1) continue;   // EOS logits of this step not here yet
+            const int B = b.B, step = r.step;
+            r.executed = step + 1;
+            if (timing_ && step > 0) { collect_timing(b, (step - 1) & 1); r.timed = step; }   // frame step-1 has fully retired
+            const float* e_now = b.h_eos_all + static_cast<size_t>(step) * B;
+            for (int i = 0; i < B; ++i) {
+                if (r.done[i]) continue;
+                const float e = e_now[i];
+                if (eos_log) (*eos_log)[r.first + i].push_back(e);
+                if (e > kEosThreshold && r.eos_step[i] < 0) r.eos_step[i] = step;                     // :596
+                if (r.eos_step[i] >= 0 && step >= r.eos_step[i] + opt_.frames_after_eos) { r.done[i] = 1; ++r.n_done; }  // :601
+            }
+            r.launched = false;
+            bool stop = r.n_done == B;   // the flow head of this step is already queued; its output is not used
+            if (!stop) {
+                for (int i = 0; i < B; ++i)
+                    if (!r.done[i]) frames_out[r.first + i]++;
+                // Every full 15-frame chunk goes to the decoder as soon as its latents are queued: the decoder never
+                // feeds back into the frame loop (the reference decodes after the loop, :640; the chunk boundaries
+                // and the carried state are the same).
+                if ((step + 1) % kDecChunk == 0) {
+                    decode_chunk(r, step + 1 - kDecChunk, kDecChunk);
+                    r.decoded = step + 1;
+                }
+                r.step = step + 1;
+                stop = r.step >= opt_.max_frames;
+            }
+            if (stop) {
+                int fmax = 0;
+                for (int i = 0; i < B; ++i) fmax = std::max(fmax, frames_out[r.first + i]);
+                for (int f0 = r.decoded; f0 < fmax; f0 += kDecChunk) decode_chunk(r, f0, std::min(kDecChunk, fmax - f0));  // :454-546
+                r.finished = true;
+                ++n_finished;
+            }
+        }
     }
-    PTTS_HIP(hipStreamSynchronize(stream_));
-    PTTS_HIP(hipStreamSynchronize(dec_stream_));
+    for (auto& r : runs) {
+        PTTS_HIP(hipStreamSynchronize(r.b->st));
+        if (timing_ && r.timed < r.executed) collect_timing(*r.b, (r.executed - 1) & 1);
+    }
+    bool dec_separate = false;
+    for (auto& r : runs) dec_separate = dec_separate || r.b->dec_st != r.b->st;
+    if (dec_separate) PTTS_HIP(hipStreamSynchronize(dec_stream_));
 }
 
-void Engine::fetch_staged(Batch& b, const std::vector<int>& frames, std::vector<UtteranceResult>& out, bool want_latents) {
+void Engine::fetch_staged(Job& job, const std::vector<int>& frames, std::vector<UtteranceResult>& out, bool want_latents) {
     std::lock_guard<std::mutex> guard(mu_);
     PTTS_HIP(hipSetDevice(opt_.device));
     const Spec& s = spec();
     const int L = s.latent, fs = s.frame_size();
-    out.resize(b.B);
-    for (int i = 0; i < b.B; ++i) {
-        out[i].frames = frames[i];
-        out[i].audio.resize(static_cast<size_t>(frames[i]) * fs);
-        if (frames[i])
-            PTTS_HIP(hipMemcpyAsync(out[i].audio.data(), b.audio_all.f() + static_cast<size_t>(i) * opt_.max_frames * fs,
-                                    out[i].audio.size() * 4, hipMemcpyDeviceToHost, stream_));
-        if (want_latents) {
-            out[i].latents.resize(static_cast<size_t>(frames[i]) * L);
+    out.resize(job.B);
+    for (size_t p = 0; p < job.parts.size(); ++p) {
+        Batch& b = *job.parts[p];
+        for (int j = 0; j < b.B; ++j) {
+            const int i = job.first[p] + j;
+            out[i].frames = frames[i];
+            out[i].audio.resize(static_cast<size_t>(frames[i]) * fs);
             if (frames[i])
-                PTTS_HIP(hipMemcpyAsync(out[i].latents.data(), b.latents.f() + static_cast<size_t>(i) * opt_.max_frames * L,
-                                        out[i].latents.size() * 4, hipMemcpyDeviceToHost, stream_));
+                PTTS_HIP(hipMemcpyAsync(out[i].audio.data(), b.audio_all.f() + static_cast<size_t>(j) * opt_.max_frames * fs,
+                                        out[i].audio.size() * 4, hipMemcpyDeviceToHost, b.st));
+            if (want_latents) {
+                out[i].latents.resize(static_cast<size_t>(frames[i]) * L);
+                if (frames[i])
+                    PTTS_HIP(hipMemcpyAsync(out[i].latents.data(), b.latents.f() + static_cast<size_t>(j) * opt_.max_frames * L,
+                                            out[i].latents.size() * 4, hipMemcpyDeviceToHost, b.st));
+            }
         }
     }
-    PTTS_HIP(hipStreamSynchronize(stream_));
+    for (Batch* b : job.parts) PTTS_HIP(hipStreamSynchronize(b->st));
 }
 
 void Engine::generate(const std::vector<Utterance>& utts, std::vector<UtteranceResult>& out, bool want_latents) {
     out.assign(utts.size(), UtteranceResult());
     if (utts.empty()) return;
     std::lock_guard<std::recursive_mutex> call(call_mu_);  // stage/run/fetch of one call must not interleave with another call's
-    Batch* b = stage(utts);
+    Job* job = stage(utts);
     std::vector<int> frames;
     std::vector<std::vector<float>> eos;
-    run_staged(*b, frames, want_latents ? &eos : nullptr);
-    fetch_staged(*b, frames, out, want_latents);
+    run_staged(*job, frames, want_latents ? &eos : nullptr);
+    fetch_staged(*job, frames, out, want_latents);
     if (want_latents)
         for (size_t i = 0; i < out.size(); ++i) out[i].eos = std::move(eos[i]);
 }
@@ -275,6 +400,7 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
     int eos_step = -1, frames = 0, pending = 0, total = 0;
     for (int step = 0; step < opt_.max_frames; ++step) {
         if (poll_cancel && cancel_flag && cancel_flag->load()) break;                      // :745-750
+        lm_bookkeeping(b);
         lm_step_dev(b, b.xcur.f(), b.cond.f(), b.eos.f());                                 // :753
         PTTS_HIP(hipMemcpyAsync(b.h_eos, b.eos.p, 4, hipMemcpyDeviceToHost, stream_));
         PTTS_HIP(hipStreamSynchronize(stream_));
@@ -414,6 +540,7 @@ void Engine::op_lm_step(Batch* b, const float* seq, float* cond, float* eos) {
     PTTS_HIP(hipSetDevice(opt_.device));
     const Spec& s = spec();
     PTTS_HIP(hipMemcpyAsync(b->xcur.p, seq, static_cast<size_t>(b->B) * s.latent * 4, hipMemcpyHostToDevice, stream_));
+    lm_bookkeeping(*b);
     lm_step_dev(*b, b->xcur.f(), b->cond.f(), b->eos.f());
     PTTS_HIP(hipMemcpyAsync(cond, b->cond.p, static_cast<size_t>(b->B) * s.d_model * 4, hipMemcpyDeviceToHost, stream_));
     PTTS_HIP(hipMemcpyAsync(eos, b->eos.p, static_cast<size_t>(b->B) * 4, hipMemcpyDeviceToHost, stream_));

@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <stdexcept>
 #include <type_traits>
 #include <vector>
@@ -197,6 +199,7 @@ __device__ __forceinline__ void norm_modulate(const float4 (&h)[2][RowMap<C>::NP
 
 struct FlowBlockArgs {
     const float* x_in = nullptr; long long x_stride = 0;   // first block of a step: latent rows feeding the input projection
+    const int* x_step = nullptr; long long x_step_stride = 0;          // optional device-side frame index added to x_in
     const float* h_prev = nullptr; float* h_next = nullptr;           // [B][C]
     const float* part_prev = nullptr; float* part_next = nullptr;     // [G][B][C]
     const float* mods = nullptr;      // this Euler step's adaLN vectors [B][mod_width]
@@ -262,9 +265,10 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
     // ---- residual stream rows of this wave
     float4 h[2][RM::NP];
     if (a.first) {
+        const float* xin = a.x_in + (a.x_step ? (long long)(*a.x_step) * a.x_step_stride : 0);
         for (int i = tid; i < 16 * L; i += kFlowThreads) {
             const int r = i / L, c = i % L;
-            const float v = r < nrows ? a.x_in[(long long)(row0 + r) * a.x_stride + c] : 0.f;
+            const float v = r < nrows ? xin[(long long)(row0 + r) * a.x_stride + c] : 0.f;
             put_act<WT>(X0, X1, r * ldx + c, v);
         }
         __syncthreads();
@@ -358,6 +362,7 @@ struct FlowFinalArgs {
     const float* h_prev = nullptr; const float* part_prev = nullptr;   // of the last block
     const float* mods = nullptr; const float* prev_b2 = nullptr;
     const float* x_in = nullptr; long long x_stride = 0;
+    const int* x_step = nullptr; long long x_step_stride = 0;
     float* x_out = nullptr;                                            // [B][L]
     const void* w_out = nullptr; const float* b_out = nullptr;
     int B = 0, blocks = 0, mod_width = 0;
@@ -396,6 +401,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_final_kernel(FlowFinalArgs 
     for (int ks = 0; ks < KSP; ++ks) mma_frag<WT>(A0, A1, lda, (kp * KSP + ks) * KSTEP, wo[ks], acc, lane);
     *(f32x4*)(red + wave * 256 + lane * 4) = acc;
     __syncthreads();
+    const float* xin = a.x_in + (a.x_step ? (long long)(*a.x_step) * a.x_step_stride : 0);
     for (int i = tid; i < 16 * L; i += kFlowThreads) {
         const int r = i / L, c = i % L;
         if (r >= nrows) continue;
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_final_kernel(FlowFinalArgs 
 #pragma unroll
         for (int k = 0; k < KPARTS; ++k) v += red[(k * NTL + tt) * 256 + ln * 4 + ri];
         const long long row = row0 + r;
-        a.x_out[row * L + c] = a.x_in[row * a.x_stride + c] + (v + a.b_out[c]) * a.dt;
+        a.x_out[row * L + c] = xin[row * a.x_stride + c] + (v + a.b_out[c]) * a.dt;
     }
 }
 
@@ -442,16 +448,16 @@ size_t flow_head_workspace_bytes(int B, int C, int wtype) {
     return ((size_t)2 * B * C + (size_t)2 * kFlowSplit * B * C) * sizeof(float);
 }
 
-template <typename K>
-static void set_lds_limit(K kernel, size_t smem) {
-    // hipFuncSetAttribute is per device; remember where it has been applied
-    static bool done[64] = {};
+// hipFuncSetAttribute is per device and per kernel; remember where it has been applied.
+static void set_lds_limit(const void* kernel, size_t smem) {
+    if (smem <= 64 * 1024) return;
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (smem > 64 * 1024 && dev >= 0 && dev < 64 && !done[dev]) {
-        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        done[dev] = true;
-    }
+    std::lock_guard<std::mutex> g(mu);
+    if (done.insert({kernel, dev}).second)
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 template <typename WT, int C, bool PF>
@@ -463,12 +469,13 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s) {
     const size_t smem_final = (size_t)T::planes * 16 * (C + T::pad) * sizeof(WT) + (size_t)kFlowWaves * 256 * 4;
     auto kb = flow_block_kernel<WT, C, G, L, PF>;
     auto kf = flow_final_kernel<WT, C, G, L>;
-    set_lds_limit(kb, smem_block);
-    set_lds_limit(kf, smem_final);
+    set_lds_limit((const void*)kb, smem_block);
+    set_lds_limit((const void*)kf, smem_final);
     float* hb[2] = {a.workspace, a.workspace + (size_t)B * C};
     float* pb[2] = {a.workspace + (size_t)2 * B * C, a.workspace + (size_t)2 * B * C + (size_t)G * B * C};
     const FlowHostTabs& tabs = *a.host_tabs;
     int cur = 0;
+    if (a.probe_a) (void)hipEventRecord(a.probe_a, s);   // the probe brackets the whole chain: steps * (blocks + 1) launches
     for (int j = 0; j < a.steps; ++j) {
         const float* mods_j = a.mods + (size_t)j * B * a.mod_width;
         const float* x_in = j == 0 ? a.x0 : a.x_out;
@@ -476,6 +483,7 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s) {
         for (int blk = 0; blk < a.blocks; ++blk) {
             FlowBlockArgs fb;
             fb.x_in = x_in; fb.x_stride = x_stride;
+            if (j == 0) { fb.x_step = a.x0_step; fb.x_step_stride = a.x0_step_stride; }
             fb.h_prev = hb[cur ^ 1]; fb.h_next = hb[cur]; fb.part_prev = pb[cur ^ 1]; fb.part_next = pb[cur];
             fb.mods = mods_j; fb.prev_b2 = blk ? tabs.b_fc2[blk - 1] : nullptr;
             fb.first = blk == 0; fb.blk = blk;
@@ -487,9 +495,30 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s) {
         }
         FlowFinalArgs ff;
         ff.h_prev = hb[cur ^ 1]; ff.part_prev = pb[cur ^ 1]; ff.mods = mods_j; ff.prev_b2 = tabs.b_fc2[a.blocks - 1];
-        ff.x_in = x_in; ff.x_stride = x_stride; ff.x_out = a.x_out; ff.w_out = a.w_out; ff.b_out = a.b_out;
+        ff.x_in = x_in; ff.x_stride = x_stride; ff.x_out = a.x_out;
+        if (j == 0) { ff.x_step = a.x0_step; ff.x_step_stride = a.x0_step_stride; } ff.w_out = a.w_out; ff.b_out = a.b_out;
         ff.B = B; ff.blocks = a.blocks; ff.mod_width = a.mod_width; ff.eps = a.eps; ff.dt = 1.0f / (float)a.steps;
         hipLaunchKernelGGL(kf, dim3(RG), dim3(kFlowThreads), smem_final, s, ff);
+    }
+    if (a.probe_b) (void)hipEventRecord(a.probe_b, s);
+}
+
+// Raises the dynamic-LDS limit of every kernel variant on the current device; call once per device outside
+// any stream capture.
+template <typename WT, int C, bool PF>
+static void prepare_chain() {
+    constexpr int G = kFlowSplit, L = 32;
+    set_lds_limit((const void*)flow_block_kernel<WT, C, G, L, PF>, 128 * 1024);
+    set_lds_limit((const void*)flow_final_kernel<WT, C, G, L>, 128 * 1024);
+}
+void flow_head_prepare(int C, int wtype) {
+    const bool bf = wtype == W_BF16;
+    switch (C) {
+        case 128: bf ? prepare_chain<__bf16, 128, true>() : prepare_chain<float, 128, false>(); break;
+        case 256: bf ? prepare_chain<__bf16, 256, true>() : prepare_chain<float, 256, false>(); break;
+        case 512: bf ? prepare_chain<__bf16, 512, true>() : prepare_chain<float, 512, false>(); break;
+        case 1024: bf ? prepare_chain<__bf16, 1024, false>() : prepare_chain<float, 1024, false>(); break;
+        default: throw std::runtime_error("flow head: flow_dim must be 128, 256, 512 or 1024");
     }
 }
 

@@ -111,8 +111,10 @@ struct FlowHostTabs {   // host arrays of per-block device pointers
     std::vector<const float*> b_fc1, b_fc2, ln_g, ln_b;
 };
 struct FlowHeadArgs {
-    const float* x0 = nullptr;    // start points, row b at x0 + b * x0_stride
+    const float* x0 = nullptr;    // start points, row b at x0 + b * x0_stride (+ *x0_step * x0_step_stride if x0_step is set)
     long long x0_stride = 0;
+    const int* x0_step = nullptr; long long x0_step_stride = 0;
+    hipEvent_t probe_a = nullptr, probe_b = nullptr;   // optional: recorded around the whole chain of steps * (blocks + 1) launches
     float* x_out = nullptr;       // [B][L]; also carries x between Euler steps (must not alias x0)
     const float* mods = nullptr;  // [steps][B][mod_width]
     int B = 0, L = 0, C = 0, blocks = 0, steps = 0, mod_width = 0;
@@ -125,6 +127,7 @@ struct FlowHeadArgs {
 };
 void launch_flow_head(const FlowHeadArgs& a, hipStream_t s);
 size_t flow_head_workspace_bytes(int B, int C, int wtype);
+void flow_head_prepare(int C, int wtype);   // once per device, outside stream capture
 // Host-side reorder of a flow-head weight W[N][K] into the fragment-major layout the kernel streams.
 std::vector<unsigned char> pack_flow_weight(const float* W, int N, int K, int wtype);
 
@@ -171,5 +174,10 @@ void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
 
 // Y[j][b][:] = silu(te[j][:] + sum_s cemb[s][b][:] + bias)   (input rows of the stacked adaLN GEMM)
 void launch_flow_mod_input(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C, hipStream_t s);
+
+// Frame bookkeeping on the device (see ops.hip): EOS logits of step *step -> h_eos_all[*step][B] in mapped host
+// memory, then h_flag = *step + 1;  latents[b][*step][:] = xcur[b][:], then *step += 1.
+void launch_publish_eos(const float* eos, int B, const int* step, float* h_eos_all, int* h_flag, hipStream_t s);
+void launch_store_latent(const float* xcur, float* latents, int B, int L, int max_frames, int* step, hipStream_t s);
 
 }  // namespace ptts
