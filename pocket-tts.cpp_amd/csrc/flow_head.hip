@@ -25,6 +25,7 @@
 // and two MFMAs per fragment, so the only rounding relative to f32 arithmetic is the weights' own storage.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <set>
@@ -208,7 +209,7 @@ struct FlowBlockArgs {
     const void* w_in = nullptr; const float* b_in = nullptr;
     const void* w1 = nullptr; const float* b1 = nullptr; const void* w2 = nullptr;
     const float* ln_g = nullptr; const float* ln_b = nullptr;
-    int B = 0, mod_width = 0;
+    int B = 0, mod_width = 0, rpg = 16;   // rpg: utterance rows per workgroup row group (<= 16, the MFMA tile height)
     float eps = 1e-6f;
 };
 
@@ -233,8 +234,8 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
     WT* X1 = X0 + (PL - 1) * 16 * ldx;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x, row0 = blockIdx.y * 16;
-    const int nrows = (a.B - row0) < 16 ? (a.B - row0) : 16;
+    const int g = blockIdx.x, row0 = blockIdx.y * a.rpg;
+    const int nrows = (a.B - row0) < a.rpg ? (a.B - row0) : a.rpg;
     const int crow = (lane >> 4) * 4, ccol = lane & 15;
     const uint4* w1p = (const uint4*)a.w1 + ((long long)g * NT1 * KS) * 64 + lane;   // + (t*KS + ks)*64
     const uint4* w2p = (const uint4*)a.w2 + ((long long)g * KS2) * 64 + lane;         // + (t*KS + ks2)*64
@@ -365,7 +366,7 @@ struct FlowFinalArgs {
     const int* x_step = nullptr; long long x_step_stride = 0;
     float* x_out = nullptr;                                            // [B][L]
     const void* w_out = nullptr; const float* b_out = nullptr;
-    int B = 0, blocks = 0, mod_width = 0;
+    int B = 0, blocks = 0, mod_width = 0, rpg = 16;
     float eps = 1e-6f, dt = 0.f;
 };
 
@@ -384,8 +385,8 @@ __global__ __launch_bounds__(kFlowThreads) void flow_final_kernel(FlowFinalArgs 
     WT* A1 = A0 + (PL - 1) * 16 * lda;
     float* red = (float*)(A0 + PL * 16 * lda);   // [waves][256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * 16;
-    const int nrows = (a.B - row0) < 16 ? (a.B - row0) : 16;
+    const int row0 = blockIdx.x * a.rpg;
+    const int nrows = (a.B - row0) < a.rpg ? (a.B - row0) : a.rpg;
     const int t = wave % NTL, kp = wave / NTL;
     uint4 wo[KSP];
 #pragma unroll
@@ -441,11 +442,22 @@ std::vector<unsigned char> pack_flow_weight(const float* W, int N, int K, int wt
     return out;
 }
 
-constexpr int kFlowSplit = 4;
+constexpr int kMaxFlowSplit = 8;
+
+// Decomposition of one residual-block launch: G workgroups per row group (column slice of fc1 / K-slice of fc2)
+// and rpg utterance rows per row group.  Smaller row groups and more slices mean more workgroups with fewer
+// bytes each (the launch is bounded by what one CU can pull in), until the partial-sum exchange (G x rows x C
+// floats per workgroup) outweighs the weight slice.  FLOW_HEAD_SPLIT / FLOW_HEAD_ROWS override for experiments.
+static void flow_head_shape(int C, int B, bool bf, int& G, int& rpg) {
+    G = 4; rpg = 16;
+    if (bf && C == 512 && B > 4) rpg = 4;   // measured at B = 64: 4 x 16 -> 627 us per chain, 4 x 4 -> 578 us, 8 x any -> 670+ us
+    if (const char* e = std::getenv("FLOW_HEAD_SPLIT")) G = std::atoi(e) == 8 && bf && C == 512 ? 8 : 4;
+    if (const char* e = std::getenv("FLOW_HEAD_ROWS")) { const int r = std::atoi(e); if (r == 4 || r == 8 || r == 16) rpg = r; }
+}
 
 size_t flow_head_workspace_bytes(int B, int C, int wtype) {
     (void)wtype;
-    return ((size_t)2 * B * C + (size_t)2 * kFlowSplit * B * C) * sizeof(float);
+    return ((size_t)2 * B * C + (size_t)2 * kMaxFlowSplit * B * C) * sizeof(float);
 }
 
 // hipFuncSetAttribute is per device and per kernel; remember where it has been applied.
@@ -460,11 +472,11 @@ static void set_lds_limit(const void* kernel, size_t smem) {
         (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-template <typename WT, int C, bool PF>
-static void run_chain(const FlowHeadArgs& a, hipStream_t s) {
-    constexpr int G = kFlowSplit, L = 32;
+template <typename WT, int C, bool PF, int G = 4>
+static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
+    constexpr int L = 32;
     using T = FlowTraits<WT>;
-    const int B = a.B, RG = (B + 15) / 16;
+    const int B = a.B, RG = (B + rpg - 1) / rpg;
     const size_t smem_block = (size_t)16 * C * 4 + (size_t)T::planes * 16 * ((C + T::pad) + (C / G + T::pad) + (L + T::pad)) * sizeof(WT);
     const size_t smem_final = (size_t)T::planes * 16 * (C + T::pad) * sizeof(WT) + (size_t)kFlowWaves * 256 * 4;
     auto kb = flow_block_kernel<WT, C, G, L, PF>;
@@ -472,7 +484,7 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s) {
     set_lds_limit((const void*)kb, smem_block);
     set_lds_limit((const void*)kf, smem_final);
     float* hb[2] = {a.workspace, a.workspace + (size_t)B * C};
-    float* pb[2] = {a.workspace + (size_t)2 * B * C, a.workspace + (size_t)2 * B * C + (size_t)G * B * C};
+    float* pb[2] = {a.workspace + (size_t)2 * B * C, a.workspace + (size_t)2 * B * C + (size_t)kMaxFlowSplit * B * C};
     const FlowHostTabs& tabs = *a.host_tabs;
     int cur = 0;
     if (a.probe_a) (void)hipEventRecord(a.probe_a, s);   // the probe brackets the whole chain: steps * (blocks + 1) launches
@@ -489,7 +501,7 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s) {
             fb.first = blk == 0; fb.blk = blk;
             fb.w_in = a.w_in; fb.b_in = a.b_in; fb.w1 = tabs.w_fc1[blk]; fb.b1 = tabs.b_fc1[blk]; fb.w2 = tabs.w_fc2[blk];
             fb.ln_g = tabs.ln_g[blk]; fb.ln_b = tabs.ln_b[blk];
-            fb.B = B; fb.mod_width = a.mod_width; fb.eps = a.eps;
+            fb.B = B; fb.mod_width = a.mod_width; fb.eps = a.eps; fb.rpg = rpg;
             hipLaunchKernelGGL(kb, dim3(G, RG), dim3(kFlowThreads), smem_block, s, fb);
             cur ^= 1;
         }
@@ -497,7 +509,7 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s) {
         ff.h_prev = hb[cur ^ 1]; ff.part_prev = pb[cur ^ 1]; ff.mods = mods_j; ff.prev_b2 = tabs.b_fc2[a.blocks - 1];
         ff.x_in = x_in; ff.x_stride = x_stride; ff.x_out = a.x_out;
         if (j == 0) { ff.x_step = a.x0_step; ff.x_step_stride = a.x0_step_stride; } ff.w_out = a.w_out; ff.b_out = a.b_out;
-        ff.B = B; ff.blocks = a.blocks; ff.mod_width = a.mod_width; ff.eps = a.eps; ff.dt = 1.0f / (float)a.steps;
+        ff.B = B; ff.blocks = a.blocks; ff.mod_width = a.mod_width; ff.eps = a.eps; ff.dt = 1.0f / (float)a.steps; ff.rpg = rpg;
         hipLaunchKernelGGL(kf, dim3(RG), dim3(kFlowThreads), smem_final, s, ff);
     }
     if (a.probe_b) (void)hipEventRecord(a.probe_b, s);
@@ -505,9 +517,9 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s) {
 
 // Raises the dynamic-LDS limit of every kernel variant on the current device; call once per device outside
 // any stream capture.
-template <typename WT, int C, bool PF>
+template <typename WT, int C, bool PF, int G = 4>
 static void prepare_chain() {
-    constexpr int G = kFlowSplit, L = 32;
+    constexpr int L = 32;
     set_lds_limit((const void*)flow_block_kernel<WT, C, G, L, PF>, 128 * 1024);
     set_lds_limit((const void*)flow_final_kernel<WT, C, G, L>, 128 * 1024);
 }
@@ -516,7 +528,10 @@ void flow_head_prepare(int C, int wtype) {
     switch (C) {
         case 128: bf ? prepare_chain<__bf16, 128, true>() : prepare_chain<float, 128, false>(); break;
         case 256: bf ? prepare_chain<__bf16, 256, true>() : prepare_chain<float, 256, false>(); break;
-        case 512: bf ? prepare_chain<__bf16, 512, true>() : prepare_chain<float, 512, false>(); break;
+        case 512:
+            if (bf) { prepare_chain<__bf16, 512, true>(); prepare_chain<__bf16, 512, true, 8>(); }
+            else prepare_chain<float, 512, false>();
+            break;
         case 1024: bf ? prepare_chain<__bf16, 1024, false>() : prepare_chain<float, 1024, false>(); break;
         default: throw std::runtime_error("flow head: flow_dim must be 128, 256, 512 or 1024");
     }
@@ -527,11 +542,17 @@ void launch_flow_head(const FlowHeadArgs& a, hipStream_t s) {
     if (a.L != 32 || a.steps <= 0 || a.blocks <= 0) throw std::runtime_error("flow head: latent_dim must be 32");
     if (!a.workspace || !a.host_tabs) throw std::runtime_error("flow head: workspace and host pointer tables are required");
     const bool bf = a.wtype == W_BF16;
+    int G = 4, rpg = 16;
+    flow_head_shape(a.C, a.B, bf, G, rpg);
     switch (a.C) {
-        case 128: bf ? run_chain<__bf16, 128, true>(a, s) : run_chain<float, 128, false>(a, s); break;
-        case 256: bf ? run_chain<__bf16, 256, true>(a, s) : run_chain<float, 256, false>(a, s); break;
-        case 512: bf ? run_chain<__bf16, 512, true>(a, s) : run_chain<float, 512, false>(a, s); break;
-        case 1024: bf ? run_chain<__bf16, 1024, false>(a, s) : run_chain<float, 1024, false>(a, s); break;
+        case 128: bf ? run_chain<__bf16, 128, true>(a, s, rpg) : run_chain<float, 128, false>(a, s, rpg); break;
+        case 256: bf ? run_chain<__bf16, 256, true>(a, s, rpg) : run_chain<float, 256, false>(a, s, rpg); break;
+        case 512:
+            if (bf && G == 8) run_chain<__bf16, 512, true, 8>(a, s, rpg);
+            else if (bf) run_chain<__bf16, 512, true>(a, s, rpg);
+            else run_chain<float, 512, false>(a, s, rpg);
+            break;
+        case 1024: bf ? run_chain<__bf16, 1024, false>(a, s, rpg) : run_chain<float, 1024, false>(a, s, rpg); break;
         default: throw std::runtime_error("flow head: flow_dim must be 128, 256, 512 or 1024");
     }
 }

@@ -1,0 +1,144 @@
+// Kernel micro-benchmarks: times single launches of the hot kernels at the shapes the B=64 frame loop and the
+// decoder use, with HIP events over many back-to-back launches.  Build: make -C pocket-tts.cpp_amd kbench
+// Usage: kbench [case ...]     cases: skinny_qkv skinny_ff1 skinny_out skinny_ff2 gemm_ada gemm_dec_qkv gemm_dec_up2
+//                                     gemm_dec_c1_2 gemm_conv0 flow attn_decode
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../csrc/kernels.h"
+
+using namespace ptts;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
+
+static void* dalloc(size_t bytes, int fill = 1) {
+    void* p = nullptr;
+    CK(hipMalloc(&p, bytes));
+    if (fill) {
+        std::vector<float> h(bytes / 4);
+        unsigned s = 12345u;
+        for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
+        CK(hipMemcpy(p, h.data(), bytes / 4 * 4, hipMemcpyHostToDevice));
+    } else {
+        CK(hipMemset(p, 0, bytes));
+    }
+    return p;
+}
+
+static double time_it(const char* name, int iters, const std::function<void(hipStream_t)>& fn, double bytes, double flops) {
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 5; ++i) fn(st);
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(a, st));
+    for (int i = 0; i < iters; ++i) fn(st);
+    CK(hipEventRecord(b, st));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    const double us = ms * 1e3 / iters;
+    std::printf("%-16s %9.2f us/launch  %8.1f GB/s  %8.2f TFLOP/s\n", name, us, bytes / us * 1e-3, flops / us * 1e-6);
+    CK(hipStreamDestroy(st));
+    return us;
+}
+
+static std::vector<float> rnd(size_t n) {
+    std::vector<float> h(n);
+    unsigned s = 777u;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (((s >> 8) & 0xffff) / 65536.0f - 0.5f) * 0.1f; }
+    return h;
+}
+
+static void* packed_weight(int N, int K, int wtype) {
+    auto w = rnd((size_t)N * K);
+    auto bytes = pack_flow_weight(w.data(), N, K, wtype);
+    void* p = nullptr;
+    CK(hipMalloc(&p, bytes.size()));
+    CK(hipMemcpy(p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    return p;
+}
+
+static void* bf16_weight(int N, int K) {
+    auto w = rnd((size_t)N * K);
+    std::vector<unsigned short> h(w.size());
+    for (size_t i = 0; i < w.size(); ++i) { unsigned u; std::memcpy(&u, &w[i], 4); h[i] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
+    void* p = nullptr;
+    CK(hipMalloc(&p, h.size() * 2));
+    CK(hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    return p;
+}
+
+static void bench_skinny(const char* name, int M, int N, int K, int splits) {
+    SkinnyArgs a;
+    a.A = (const float*)dalloc((size_t)M * K * 4); a.lda = K;
+    a.Wp = packed_weight(N, K, W_BF16); a.wtype = W_BF16;
+    a.M = M; a.N = N; a.K = K; a.splits = splits;
+    if (splits > 1) a.P = (float*)dalloc((size_t)splits * M * N * 4, 0);
+    else { a.C = (float*)dalloc((size_t)M * N * 4, 0); a.ldc = N; }
+    time_it(name, 300, [&](hipStream_t s) { launch_skinny_gemm(a, s); }, (double)N * K * 2 + (double)M * K * 4 + (double)M * N * 4 * splits, 2.0 * M * N * K);
+}
+
+static void bench_gemm(const char* name, int M, int N, int K, int split_a, int lda = 0) {
+    GemmArgs g;
+    if (!lda) lda = K;
+    g.A = (const float*)dalloc(((size_t)M * lda + K) * 4); g.lda = lda;
+    g.W = bf16_weight(N, K); g.wtype = W_BF16;
+    g.C = (float*)dalloc((size_t)M * N * 4, 0); g.ldc = N;
+    g.M = M; g.N = N; g.K = K; g.split_a = split_a;
+    time_it(name, 50, [&](hipStream_t s) { launch_gemm(g, s); }, (double)N * K * 2 + (double)M * lda * 4 + (double)M * N * 4, 2.0 * M * N * K);
+}
+
+static void bench_flow(int B) {
+    const int C = 512, L = 32, nb = 6, steps = 10, mw = nb * 3 * C + 2 * C;
+    FlowHostTabs tabs;
+    for (int i = 0; i < nb; ++i) {
+        tabs.w_fc1.push_back(packed_weight(C, C, W_BF16));
+        tabs.w_fc2.push_back(packed_weight(C, C, W_BF16));
+        tabs.b_fc1.push_back((const float*)dalloc(C * 4)); tabs.b_fc2.push_back((const float*)dalloc(C * 4));
+        tabs.ln_g.push_back((const float*)dalloc(C * 4)); tabs.ln_b.push_back((const float*)dalloc(C * 4));
+    }
+    FlowHeadArgs a;
+    a.x0 = (const float*)dalloc((size_t)B * L * 4); a.x0_stride = L;
+    a.x_out = (float*)dalloc((size_t)B * L * 4, 0);
+    a.mods = (const float*)dalloc((size_t)steps * B * mw * 4);
+    a.B = B; a.L = L; a.C = C; a.blocks = nb; a.steps = steps; a.mod_width = mw;
+    a.w_in = packed_weight(C, L, W_BF16); a.b_in = (const float*)dalloc(C * 4);
+    a.w_out = packed_weight(L, C, W_BF16); a.b_out = (const float*)dalloc(L * 4);
+    a.host_tabs = &tabs; a.workspace = (float*)dalloc(flow_head_workspace_bytes(B, C, W_BF16), 0); a.wtype = W_BF16;
+    flow_head_prepare(C, W_BF16);
+    const double us = time_it("flow_chain", 30, [&](hipStream_t s) { launch_flow_head(a, s); }, 0, 2.0 * B * steps * (2.0 * L * C + nb * 2.0 * C * C));
+    std::printf("   = %.2f us per launch over %d launches\n", us / (steps * (nb + 1)), steps * (nb + 1));
+}
+
+int main(int argc, char** argv) {
+    std::vector<std::string> cases;
+    for (int i = 1; i < argc; ++i) cases.push_back(argv[i]);
+    auto want = [&](const char* c) {
+        if (cases.empty()) return true;
+        for (auto& s : cases) if (s == c) return true;
+        return false;
+    };
+    CK(hipSetDevice(0));
+    if (want("skinny_qkv")) bench_skinny("skinny_qkv", 64, 3072, 1024, 1);
+    if (want("skinny_ff1")) bench_skinny("skinny_ff1", 64, 4096, 1024, 1);
+    if (want("skinny_out")) bench_skinny("skinny_out", 64, 1024, 1024, 4);
+    if (want("skinny_ff2")) bench_skinny("skinny_ff2", 64, 1024, 4096, 16);
+    if (want("gemm_ada")) bench_gemm("gemm_ada", 640, 10240, 512, 1);
+    if (want("gemm_dec_qkv")) bench_gemm("gemm_dec_qkv", 15360, 1536, 512, 0);
+    if (want("gemm_dec_ff2")) bench_gemm("gemm_dec_ff2", 15360, 512, 2048, 0);
+    if (want("gemm_conv0")) bench_gemm("gemm_conv0", 15360, 512, 3584, 0, 512);
+    if (want("gemm_dec_up1")) bench_gemm("gemm_dec_up1", 92160, 640, 512, 0, 256);
+    if (want("gemm_dec_up2")) bench_gemm("gemm_dec_up2", 460800, 256, 256, 0, 128);
+    if (want("gemm_dec_c1_2")) bench_gemm("gemm_dec_c1_2", 1843200, 32, 192, 0, 64);
+    if (want("gemm_dec_c2_2")) bench_gemm("gemm_dec_c2_2", 1843200, 64, 32, 0, 32);
+    if (want("flow")) bench_flow(64);
+    return 0;
+}
