@@ -130,6 +130,9 @@ POCKET_TTS_API int ptts_audio_normalize(const float* in, int n, float* out);
  * [3] the flow head's launch chain alone (lsd_steps * (blocks + 1) launches per frame, counted in calls[3]);
  * times_ms = totals, calls = number of launches of each. */
 POCKET_TTS_API int ptts_phase_timing(PocketTTSHandle handle, int enable);
+/* Coalescing of concurrent single-utterance calls (pocket_tts_generate, pocket_tts_generate_ids with n = 1):
+ * stats[0] = batches run, stats[1] = utterances served, stats[2] = largest batch. */
+POCKET_TTS_API int ptts_scheduler_stats(PocketTTSHandle handle, long* stats);
 POCKET_TTS_API int ptts_phase_times(PocketTTSHandle handle, double* times_ms, long* calls);
 /* bytes[0..3] = GEMM weight bytes (compute precision) of the LM, the flow head, the decoder, the encoder */
 POCKET_TTS_API int ptts_weight_bytes(PocketTTSHandle handle, unsigned long long* bytes);

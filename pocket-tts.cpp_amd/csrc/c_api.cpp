@@ -261,7 +261,12 @@ POCKET_TTS_API int pocket_tts_generate_ids(PocketTTSHandle handle, int n, const 
             utts[i].noise = noise ? noise[i] : nullptr;
         }
         std::vector<ptts::UtteranceResult> res;
-        tts->engine().generate(utts, res, want);
+        if (n == 1) {   // single utterances go through the coalescing queue like pocket_tts_generate
+            res.resize(1);
+            tts->engine().generate_one(utts[0], res[0], want);
+        } else {
+            tts->engine().generate(utts, res, want);
+        }
         for (int i = 0; i < n; ++i) {
             if (results) fill_result(&results[i], res[i].audio, tts->engine().spec().sample_rate);
             if (frames_out) frames_out[i] = res[i].frames;
@@ -484,6 +489,15 @@ POCKET_TTS_API int ptts_phase_times(PocketTTSHandle handle, double* times_ms, lo
         auto t = tts_of(handle)->engine().phase_times();
         times_ms[0] = t.lm_ms; times_ms[1] = t.flow_ms; times_ms[2] = t.dec_ms; times_ms[3] = t.head_ms;
         calls[0] = t.lm_calls; calls[1] = t.flow_calls; calls[2] = t.dec_calls; calls[3] = t.head_calls;
+        return 0;
+    });
+}
+
+POCKET_TTS_API int ptts_scheduler_stats(PocketTTSHandle handle, long* stats) {
+    if (!handle || !stats) { set_error("Invalid parameters"); return -1; }
+    return guarded("scheduler_stats: ", [&] {
+        auto st = tts_of(handle)->engine().scheduler_stats();
+        stats[0] = st.batches; stats[1] = st.utterances; stats[2] = st.largest;
         return 0;
     });
 }

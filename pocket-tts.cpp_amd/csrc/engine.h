@@ -5,7 +5,10 @@
 #pragma once
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <random>
@@ -123,6 +126,12 @@ public:
     // ---- whole-path entry points (lock-step batch of independent utterances) ----
     // Offline: /root/reference/src/pocket_tts.cpp:548-657 for every utterance of the batch.
     void generate(const std::vector<Utterance>& utts, std::vector<UtteranceResult>& out, bool want_latents);
+    // One utterance from any thread.  Calls that arrive while a batch is running are queued and leave together
+    // as the next lock-step batch (up to kMaxCoalesce), so concurrent callers of the single-utterance API share
+    // the GPU instead of taking turns (scheduler.cpp).
+    void generate_one(const Utterance& utt, UtteranceResult& out, bool want_latents);
+    struct SchedulerStats { long batches = 0, utterances = 0, largest = 0; };
+    SchedulerStats scheduler_stats();
     // The same in three parts, so a benchmark can time the device-resident middle on its own:
     //   stage (host -> HBM), run_staged (prefill + frame loop + decode, audio left in HBM), fetch_staged (HBM -> host).
     // Hold call_mutex() across the three when other threads may use the engine.
@@ -208,6 +217,14 @@ private:
     int lanes_ = 1;
     bool use_graph_ = true;                     // replay each frame as one hipGraph (POCKET_TTS_NO_GRAPH=1: eager launches)
     Job job_;
+    // coalescing queue of generate_one
+    struct Pending { const Utterance* utt; UtteranceResult* out; bool want_latents; std::exception_ptr err; bool done = false; };
+    static constexpr size_t kMaxCoalesce = 64;
+    std::mutex q_mu_;
+    std::condition_variable q_cv_;
+    std::deque<Pending*> queue_;
+    bool leader_active_ = false;
+    SchedulerStats sched_stats_;
     std::mutex ev_mu_;
     bool timing_ = false;
     hipEvent_t ev_[2] = {nullptr, nullptr};

@@ -120,9 +120,9 @@ std::vector<float> PocketTTS::generateWithEmbeddings(const std::string& text, co
     u.token_ids = impl_->tokenize(text);
     u.voice = voiceEmbeddings.data();
     u.voice_frames = impl_->frames_of(voiceEmbeddings, voiceEmbeddingShape);
-    std::vector<ptts::UtteranceResult> res;
-    impl_->engine->generate({u}, res, false);
-    return std::move(res[0].audio);
+    ptts::UtteranceResult res;
+    impl_->engine->generate_one(u, res, false);   // coalesces with concurrent callers
+    return std::move(res.audio);
 }
 
 int PocketTTS::generateStreaming(const std::string& text, const std::vector<float>& voiceEmbeddings,

@@ -1,0 +1,95 @@
+"""Concurrent callers of the single-utterance entry points share lock-step batches (host scheduler), and the
+drop-in C API end to end: pocket_tts_create -> encode_voice_from_samples -> generate / generate_streaming with
+a SentencePiece model and a weight pack in the reference's directory layout."""
+import ctypes as C
+import os
+import shutil
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_concurrent_single_calls_are_coalesced(packs):
+    import ptts_lib
+    path, spec, _ = packs["tiny"]
+    F = 10
+    eng = ptts_lib.Engine(path, precision="fp32", temperature=0.0, lsd_steps=4, max_frames=F)
+    rng = np.random.default_rng(3)
+    n = 12
+    ids = [rng.integers(0, spec.vocab, int(rng.integers(3, 15))).astype(np.int64) for _ in range(n)]
+    voices = [(rng.standard_normal((int(rng.integers(1, 9)), spec.d_model)) * 0.5).astype(np.float32) for _ in range(n)]
+    solo = [eng.generate_ids([ids[i]], [voices[i]])[0] for i in range(n)]
+    before = eng.scheduler_stats()
+    assert before["batches"] == n and before["largest"] == 1
+    out = [None] * n
+    errs = []
+    gate = threading.Barrier(n)
+
+    def work(i):
+        try:
+            gate.wait()
+            out[i] = eng.generate_ids([ids[i]], [voices[i]])[0]
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    after = eng.scheduler_stats()
+    assert after["utterances"] - before["utterances"] == n
+    assert after["batches"] - before["batches"] < n, "no two concurrent calls shared a batch"
+    assert after["largest"] > 1
+    for i in range(n):
+        assert out[i]["frames"] == solo[i]["frames"] == F
+        assert out[i]["audio"].shape == solo[i]["audio"].shape
+        # same utterance alone or inside a batch: early frames agree to rounding (later ones drift, the loop is chaotic)
+        assert np.abs(out[i]["latents"][:3] - solo[i]["latents"][:3]).max() < 1e-3
+    # an invalid request fails alone, before it can join a batch
+    with pytest.raises(ptts_lib.PttsError, match="Text cannot be empty"):
+        eng.generate_ids([np.zeros(0, np.int64)], [voices[0]])
+    eng.close()
+
+
+def test_drop_in_c_api_end_to_end(packs, tmp_path):
+    import ptts_lib
+    L = ptts_lib.load()
+    path, spec, _ = packs["small"]
+    models = tmp_path / "models" / "onnx"
+    models.mkdir(parents=True)
+    shutil.copy(path, models / "pocket_tts.ptts")
+    tok = os.path.join(ROOT, "tests", "golden", "sp_unigram.model")
+    cfg = ptts_lib.PocketTTSConfig(models_dir=str(models).encode(), tokenizer_path=tok.encode(), precision=b"fp32",
+                                   temperature=0.5, lsd_steps=4, max_frames=7)
+    h = L.pocket_tts_create(C.byref(cfg))
+    assert h, L.pocket_tts_get_last_error()
+    clip = (np.sin(np.arange(16000) / 9.0) * 0.4).astype(np.float32)
+    v = L.pocket_tts_encode_voice_from_samples(h, clip, len(clip), 16000)     # resampled to 24 kHz inside
+    assert v, L.pocket_tts_get_last_error()
+    assert L.pocket_tts_voice_frames(v) == int(np.ceil(24000 / spec.frame_size))
+    res = ptts_lib.AudioResult()
+    assert L.pocket_tts_generate(h, b"hello from the test", v, C.byref(res)) == 0, L.pocket_tts_get_last_error()
+    assert res.sample_rate == 24000 and res.sample_count == 7 * spec.frame_size     # EOS never fires with this pack
+    audio = np.ctypeslib.as_array(res.data, shape=(res.sample_count,)).copy()
+    assert np.isfinite(audio).all() and np.abs(audio).max() > 0
+    L.pocket_tts_free_audio(C.byref(res))
+    assert not res.data and res.sample_count == 0
+    # streaming: chunk 3 over 7 frames -> 3, 3 and a final flush of 1
+    got = []
+    cb = ptts_lib.CHUNK_CB(lambda p, n, fin, u: got.append((n, fin)))
+    sc = ptts_lib.StreamingConfig(chunk_size_frames=3, user_data=None)
+    total = L.pocket_tts_generate_streaming(h, b"hello from the test", v, cb, C.byref(sc))
+    assert total == 7 * spec.frame_size
+    assert got == [(3 * spec.frame_size, 0), (3 * spec.frame_size, 0), (spec.frame_size, 1)]
+    # empty text is an error reported through get_last_error, not a crash
+    assert L.pocket_tts_generate(h, b"   ", v, C.byref(res)) == -1
+    assert b"Text cannot be empty" in L.pocket_tts_get_last_error()
+    L.pocket_tts_free_voice(v)
+    L.pocket_tts_destroy(h)
