@@ -129,6 +129,11 @@ POCKET_TTS_API int ptts_audio_normalize(const float* in, int n, float* out);
  * [0] LM frame step (kernel chain), [1] flow phase (adaLN GEMMs + fused head), [2] decoder chunk,
  * [3] the flow head's launch chain alone (lsd_steps * (blocks + 1) launches per frame, counted in calls[3]);
  * times_ms = totals, calls = number of launches of each. */
+/* The int8 matrix product of the "int8" precision on its own: out[M][N] = A[M][K] . W[N][K]^T with W quantised per
+ * output row to int8 and A per row and per block of 64 k (K % 64 == 0, N % 16 == 0).  For checking the kernel's
+ * arithmetic exactly; the model paths call the same kernel. */
+POCKET_TTS_API int ptts_q8_linear(PocketTTSHandle handle, const float* A, int M, int K, const float* W, int N, float* out);
+
 POCKET_TTS_API int ptts_phase_timing(PocketTTSHandle handle, int enable);
 /* Coalescing of concurrent single-utterance calls (pocket_tts_generate, pocket_tts_generate_ids with n = 1):
  * stats[0] = batches run, stats[1] = utterances served, stats[2] = largest batch. */

@@ -34,6 +34,7 @@ def lib() -> C.CDLL:
         L.ptts_oracle_load.restype = C.c_void_p
         L.ptts_oracle_load.argtypes = [C.c_char_p]
         L.ptts_oracle_free.argtypes = [C.c_void_p]
+        L.ptts_oracle_enable_q8.argtypes = [C.c_void_p]
         L.ptts_oracle_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.ptts_oracle_text_conditioner.argtypes = [C.c_void_p, i64p, C.c_int, f32p]
         L.ptts_oracle_lm_state_new.restype = C.c_void_p
@@ -66,11 +67,13 @@ def _ptr(a):
 class Oracle:
     """One loaded weight pack plus the five graph functions and the orchestration."""
 
-    def __init__(self, pack_path: str):
+    def __init__(self, pack_path: str, int8: bool = False):
         self.L = lib()
         self.h = self.L.ptts_oracle_load(pack_path.encode())
         if not self.h:
             raise RuntimeError(f"oracle: cannot load pack {pack_path}")
+        if int8:   # LM-layer and flow-block matrices in the engine's int8 scheme (see ptts_oracle.c, linear_q8)
+            self.L.ptts_oracle_enable_q8(self.h)
         d = (C.c_int * 6)()
         self.L.ptts_oracle_dims(self.h, d)
         self.latent, self.d_model, self.frame_size, self.vocab, self.mimi_dim, self.sample_rate = list(d)

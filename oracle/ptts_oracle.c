@@ -109,8 +109,11 @@ Oracle *ptts_oracle_load(const char *path) {
     return o;
 }
 
+static void q8_forget(const unsigned char *lo, const unsigned char *hi);
+
 void ptts_oracle_free(Oracle *o) {
     if (!o) return;
+    q8_forget(o->blob, o->blob + o->blob_size);
     free(o->blob);
     free(o);
 }
@@ -122,6 +125,22 @@ void ptts_oracle_dims(const Oracle *o, int *dims) {
 }
 
 /* ------------------------------------------------------------------ math helpers */
+
+static void q8_register(const float *W, int N, int K);
+
+/* Switches this oracle's LM-layer and flow-block matrices to the int8 scheme described at linear_q8. */
+void ptts_oracle_enable_q8(Oracle *o) {
+    const Spec *s = &o->s;
+    const char *lm[4] = {"qkv.w", "out.w", "ff1.w", "ff2.w"};
+    const int lmN[4] = {3 * s->d_model, s->d_model, s->lm_ffn, s->d_model};
+    const int lmK[4] = {s->d_model, s->d_model, s->d_model, s->lm_ffn};
+    for (int l = 0; l < s->lm_layers; ++l)
+        for (int j = 0; j < 4; ++j) q8_register(tensorf(o, "%s%d.%s", "lm.l", l, lm[j]), lmN[j], lmK[j]);
+    for (int b = 0; b < s->flow_blocks && s->flow_dim % 256 == 0; ++b) {   /* narrower heads keep bf16 blocks */
+        q8_register(tensorf(o, "%s%d.%s", "flow.b", b, "fc1.w"), s->flow_dim, s->flow_dim);
+        q8_register(tensorf(o, "%s%d.%s", "flow.b", b, "fc2.w"), s->flow_dim, s->flow_dim);
+    }
+}
 
 static float dotf(const float *a, const float *b, int n) {
     float acc[16] = {0};
@@ -136,9 +155,96 @@ static float dotf(const float *a, const float *b, int n) {
     return ((s4[0] + s4[2]) + (s4[1] + s4[3])) + tail;
 }
 
+/* ------------------------------------------------------------------ int8 mode (the engine's "int8" precision)
+ *
+ * The reference's int8 graphs (flow_lm_main_int8.onnx, flow_lm_flow_int8.onnx, src/pocket_tts.cpp:90-96) are
+ * ONNX Runtime quantised models whose exact scheme cannot be read offline; the scheme restated here is the one
+ * the HIP engine implements, so the two can be compared exactly:
+ *   weights      per output channel n: sw[n] = max|W[n][:]| / 127, qw = rint(W * 127 / max) in [-127, 127]
+ *   activations  per row and per block of 64 consecutive k: s = max|x|, qx = rint(x * (127 / s)), d = s / 127
+ *   product      y[n] = (sum over blocks of (float)(sum_k qx*qw) * d) * sw[n] + bias[n], blocks in k order
+ * Applied to the LM layers' qkv/out/ff1/ff2 and (when flow_dim is a multiple of 256) the flow head's fc1/fc2
+ * matrices; every other matrix keeps its bf16-rounded weights.  A quantised matrix is recognised by its address in the weight blob. */
+typedef struct { const float *W; int N, K; int8_t *q; float *sw; } Q8Entry;
+static Q8Entry g_q8[128];
+static int g_nq8 = 0;
+
+static const Q8Entry *q8_find(const float *W) {
+    for (int i = 0; i < g_nq8; ++i)
+        if (g_q8[i].W == W) return &g_q8[i];
+    return NULL;
+}
+
+static void q8_register(const float *W, int N, int K) {
+    if (q8_find(W) || g_nq8 >= 128 || K % 64) return;
+    Q8Entry *e = &g_q8[g_nq8];
+    e->W = W; e->N = N; e->K = K;
+    e->q = (int8_t *)malloc((size_t)N * K);
+    e->sw = (float *)malloc((size_t)N * sizeof(float));
+    for (int n = 0; n < N; ++n) {
+        float mx = 0.f;
+        for (int k = 0; k < K; ++k) { float a = fabsf(W[(size_t)n * K + k]); if (a > mx) mx = a; }
+        const float inv = mx > 0.f ? 127.0f / mx : 0.f;
+        e->sw[n] = mx / 127.0f;
+        for (int k = 0; k < K; ++k) {
+            float r = rintf(W[(size_t)n * K + k] * inv);
+            if (r > 127.f) r = 127.f;
+            if (r < -127.f) r = -127.f;
+            e->q[(size_t)n * K + k] = (int8_t)r;
+        }
+    }
+    ++g_nq8;
+}
+
+/* drop the entries that point into a blob about to be freed */
+static void q8_forget(const unsigned char *lo, const unsigned char *hi) {
+    int w = 0;
+    for (int i = 0; i < g_nq8; ++i) {
+        const unsigned char *p = (const unsigned char *)g_q8[i].W;
+        if (p >= lo && p < hi) { free(g_q8[i].q); free(g_q8[i].sw); continue; }
+        g_q8[w++] = g_q8[i];
+    }
+    g_nq8 = w;
+}
+
+static void linear_q8(float *Y, int ldy, const float *X, int ldx, const Q8Entry *e, const float *bias, int M) {
+    const int N = e->N, K = e->K, KB = K / 64;
+#pragma omp parallel for schedule(static) if ((long)M * N * K > 400000)
+    for (int m = 0; m < M; ++m) {
+        int8_t *qx = (int8_t *)malloc((size_t)K);
+        float *d = (float *)malloc((size_t)KB * sizeof(float));
+        const float *x = X + (long)m * ldx;
+        for (int kb = 0; kb < KB; ++kb) {
+            float s = 0.f;
+            for (int k = 0; k < 64; ++k) { float a = fabsf(x[kb * 64 + k]); if (a > s) s = a; }
+            const float inv = s > 0.f ? 127.0f / s : 0.f;
+            d[kb] = s / 127.0f;
+            for (int k = 0; k < 64; ++k) {
+                float r = rintf(x[kb * 64 + k] * inv);
+                if (r > 127.f) r = 127.f;
+                if (r < -127.f) r = -127.f;
+                qx[kb * 64 + k] = (int8_t)r;
+            }
+        }
+        for (int n = 0; n < N; ++n) {
+            const int8_t *qw = e->q + (size_t)n * K;
+            float acc = 0.f;
+            for (int kb = 0; kb < KB; ++kb) {
+                int isum = 0;
+                for (int k = 0; k < 64; ++k) isum += (int)qx[kb * 64 + k] * (int)qw[kb * 64 + k];
+                acc += (float)isum * d[kb];
+            }
+            Y[(long)m * ldy + n] = acc * e->sw[n] + (bias ? bias[n] : 0.f);
+        }
+        free(qx); free(d);
+    }
+}
+
 /* Y[m][n] = bias[n] + sum_k X[m*ldx + k] * W[n][k]   (rows of X may overlap: ldx < K is allowed) */
 static void linear(float *Y, int ldy, const float *X, int ldx, const float *W, const float *bias,
                    int M, int N, int K) {
+    const Q8Entry *qe = g_nq8 ? q8_find(W) : NULL;
+    if (qe) { linear_q8(Y, ldy, X, ldx, qe, bias, M); return; }
     long work = (long)M * N * K;
 #pragma omp parallel for collapse(2) schedule(static) if (work > 400000)
     for (int m = 0; m < M; ++m)

@@ -493,6 +493,14 @@ POCKET_TTS_API int ptts_phase_times(PocketTTSHandle handle, double* times_ms, lo
     });
 }
 
+POCKET_TTS_API int ptts_q8_linear(PocketTTSHandle handle, const float* A, int M, int K, const float* W, int N, float* out) {
+    if (!handle || !A || !W || !out || M <= 0 || N <= 0 || K <= 0) { set_error("Invalid parameters"); return -1; }
+    return guarded("q8_linear: ", [&] {
+        tts_of(handle)->engine().q8_linear(A, M, K, W, N, out);
+        return 0;
+    });
+}
+
 POCKET_TTS_API int ptts_scheduler_stats(PocketTTSHandle handle, long* stats) {
     if (!handle || !stats) { set_error("Invalid parameters"); return -1; }
     return guarded("scheduler_stats: ", [&] {

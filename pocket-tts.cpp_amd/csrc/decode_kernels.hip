@@ -18,8 +18,10 @@
 // mantissa bits, so the only rounding left relative to f32 arithmetic is the weights' own bf16 storage.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <stdexcept>
 #include <type_traits>
+#include <vector>
 
 #include "kernels.h"
 
@@ -155,15 +157,152 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     }
 }
 
+// ---- int8 weights x int8 activations (v_mfma_i32_16x16x64_i8) --------------------------------------------------
+// Activations are quantised while they are staged: per row and per block of 64 consecutive k,
+// s = max|a|, q = rint(a * 127 / s), d = s / 127; the integer block products are exact, and
+// y[n] = (sum over blocks of (float)isum * d) * wscale[n] + bias[n].  A block is held by 16 consecutive lanes
+// (one float4 each), so its maximum is four shuffles.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+__device__ __forceinline__ unsigned quantize4(const float4 v, float inv) {
+    const int q0 = (int)rintf(v.x * inv), q1 = (int)rintf(v.y * inv), q2 = (int)rintf(v.z * inv), q3 = (int)rintf(v.w * inv);
+    return (unsigned)(q0 & 0xff) | ((unsigned)(q1 & 0xff) << 8) | ((unsigned)(q2 & 0xff) << 16) | ((unsigned)(q3 & 0xff) << 24);
+}
+
+__device__ __forceinline__ float block_absmax16(const float4 v) {
+    float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
+    m = fmaxf(m, __shfl_xor(m, 4, 64));
+    m = fmaxf(m, __shfl_xor(m, 8, 64));
+    return m;
+}
+
+__global__ __launch_bounds__(256) void skinny_q8_kernel(SkinnyArgs a) {
+    constexpr int KSTEP = 64, KCH = 128, LDA = KCH + 16, NKS = KCH / KSTEP, PIECES = KCH / 4, APT = 64 * PIECES / 256;
+    __shared__ __attribute__((aligned(16))) signed char As[2][64 * LDA];
+    __shared__ __attribute__((aligned(16))) float Dq[2][NKS][64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x * 4 + wave;
+    const bool tile_live = nt * 16 < a.N;
+    const int m0 = blockIdx.z * 64;
+    const int Kc = a.K / a.splits;
+    const int k_begin = blockIdx.y * Kc;
+    const int nchunks = (Kc + KCH - 1) / KCH;
+    const int KS_total = a.K / KSTEP;
+    const uint4* wbase = (const uint4*)a.Wp + (long long)nt * KS_total * 64 + lane;
+
+    float4 areg[APT];
+    uint4 bnext[NKS], bcur[NKS];
+    auto load_chunk = [&](int c) {
+        const int kc0 = c * KCH;
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int id = tid + 256 * i, row = id / PIECES, piece = id % PIECES;
+            const int k = kc0 + piece * 4;
+            const bool ok = (m0 + row) < a.M && k < Kc;
+            areg[i] = ok ? *(const float4*)(a.A + (long long)(m0 + row) * a.lda + k_begin + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NKS; ++i) {
+            const int k = kc0 + i * KSTEP;
+            bnext[i] = (tile_live && k < Kc) ? wbase[(long long)((k_begin + k) / KSTEP) * 64] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, g = lane >> 4;
+
+    load_chunk(0);
+    for (int c = 0; c < nchunks; ++c) {
+        signed char* buf = As[c & 1];
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int id = tid + 256 * i, row = id / PIECES, piece = id % PIECES;
+            const float m = block_absmax16(areg[i]);
+            const float inv = m > 0.f ? 127.0f / m : 0.f;
+            *(unsigned*)(buf + row * LDA + piece * 4) = quantize4(areg[i], inv);
+            if ((piece & 15) == 0) Dq[c & 1][piece >> 4][row] = m / 127.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < NKS; ++i) bcur[i] = bnext[i];
+        __syncthreads();
+        if (c + 1 < nchunks) load_chunk(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const i32x4 b4 = __builtin_bit_cast(i32x4, bcur[ks]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const i32x4 a4 = *(const i32x4*)(buf + (mt * 16 + r) * LDA + ks * 64 + 16 * g);
+                const i32x4 z = {0, 0, 0, 0};
+                const i32x4 ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a4, b4, z, 0, 0, 0);
+                const float4 d4 = *(const float4*)(&Dq[c & 1][ks][mt * 16 + 4 * g]);
+                acc[mt][0] += (float)ci[0] * d4.x; acc[mt][1] += (float)ci[1] * d4.y;
+                acc[mt][2] += (float)ci[2] * d4.z; acc[mt][3] += (float)ci[3] * d4.w;
+            }
+        }
+    }
+    if (!tile_live) return;
+    const int col = nt * 16 + r;
+    const float ws = a.wscale[col];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + mt * 16 + g * 4 + i;
+            if (row >= a.M) continue;
+            float v = acc[mt][i] * ws;
+            if (a.P) {
+                a.P[((long long)blockIdx.y * a.M + row) * a.N + col] = v;
+            } else {
+                if (a.bias) v += a.bias[col];
+                a.C[(long long)row * a.ldc + col] = act_dev(v, a.act);
+            }
+        }
+    }
+}
+
+// int8 fragment-major packing: tile (nt, ks) holds, for lane l, the 16 consecutive k-values ks*64 + 16*(l>>4) ..
+// of output column nt*16 + (l&15).
+std::vector<unsigned char> pack_q8_weight(const float* W, int N, int K, std::vector<float>& scale) {
+    if (N % 16 || K % 64) throw std::runtime_error("int8 weight: N must be a multiple of 16 and K of 64");
+    std::vector<unsigned char> out((size_t)N * K);
+    scale.assign(N, 0.f);
+    std::vector<signed char> q((size_t)N * K);
+    for (int n = 0; n < N; ++n) {
+        float mx = 0.f;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, fabsf(W[(size_t)n * K + k]));
+        const float inv = mx > 0.f ? 127.0f / mx : 0.f;
+        scale[n] = mx / 127.0f;
+        for (int k = 0; k < K; ++k) {
+            float rv = rintf(W[(size_t)n * K + k] * inv);
+            rv = fminf(fmaxf(rv, -127.f), 127.f);
+            q[(size_t)n * K + k] = (signed char)rv;
+        }
+    }
+    const int KS = K / 64;
+    for (int nt = 0; nt < N / 16; ++nt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 16; ++j)
+                    out[(((size_t)nt * KS + ks) * 64 + l) * 16 + j] = (unsigned char)q[(size_t)(nt * 16 + (l & 15)) * K + ks * 64 + 16 * (l >> 4) + j];
+    return out;
+}
+
 void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return;
     const bool bf = a.wtype == W_BF16;
-    const int kstep = bf ? 32 : 16;
+    const int kstep = a.wtype == W_I8 ? 64 : bf ? 32 : 16;
+    if (a.wtype == W_I8 && !a.wscale) throw std::runtime_error("skinny gemm: int8 weights need their scales");
     if (a.N % 16 || a.K % kstep || a.splits <= 0 || a.K % a.splits || (a.K / a.splits) % kstep || (a.lda % 4) || ((uintptr_t)a.A & 15))
         throw std::runtime_error("skinny gemm: shape not tileable (N % 16, K % k-step, K % splits, lda alignment)");
     if (!a.P && a.splits != 1) throw std::runtime_error("skinny gemm: split K needs a partial buffer");
     dim3 grid((a.N + 63) / 64, a.splits, (a.M + 63) / 64), block(256);
-    if (bf) hipLaunchKernelGGL(skinny_gemm_kernel<__bf16>, grid, block, 0, s, a);
+    if (a.wtype == W_I8) hipLaunchKernelGGL(skinny_q8_kernel, grid, block, 0, s, a);
+    else if (bf) hipLaunchKernelGGL(skinny_gemm_kernel<__bf16>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(skinny_gemm_kernel<float>, grid, block, 0, s, a);
 }
 

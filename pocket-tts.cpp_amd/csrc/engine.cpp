@@ -93,7 +93,7 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
         e.shape = t.shape;
         e.off_f32 = f32_bytes;
         f32_bytes += align256(t.numel() * 4);
-        if (prec_ == Precision::BF16 && is_gemm_weight(n)) {
+        if (prec_ != Precision::FP32 && is_gemm_weight(n)) {
             e.has_lp = true;
             e.off_lp = lp_bytes;
             lp_bytes += align256(t.numel() * 2);
@@ -109,7 +109,7 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     size_t ada_b_off = f32_bytes;
     f32_bytes += align256(static_cast<size_t>(mod_width) * 4);
     size_t ada_off_lp = lp_bytes;
-    if (prec_ == Precision::BF16) lp_bytes += align256(ada_w_elems * 2);
+    if (prec_ != Precision::FP32) lp_bytes += align256(ada_w_elems * 2);
 
     std::vector<unsigned char> host(f32_bytes, 0);
     for (auto& n : names) {
@@ -131,7 +131,7 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     }
     blob_f32_.alloc(f32_bytes);
     PTTS_HIP(hipMemcpy(blob_f32_.p, host.data(), f32_bytes, hipMemcpyHostToDevice));
-    if (prec_ == Precision::BF16) {
+    if (prec_ != Precision::FP32) {
         std::vector<uint16_t> lp(lp_bytes / 2, 0);
         auto conv = [&](size_t off_lp, const float* src, size_t n) {
             uint16_t* d = lp.data() + off_lp / 2;
@@ -154,7 +154,23 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
 
     // fused flow head: fragment-major copies of its sequential weights + per-block pointer tables
     const int nb = s.flow_blocks;
-    flow_wtype = prec_ == Precision::BF16 ? W_BF16 : W_F32;
+    flow_wtype = prec_ != Precision::FP32 ? W_BF16 : W_F32;
+    const bool q8 = prec_ == Precision::INT8;
+    lm_wtype = q8 ? W_I8 : flow_wtype;
+    flow_block_wtype = (q8 && s.flow_dim % 256 == 0) ? W_I8 : flow_wtype;   // narrower heads keep bf16 blocks
+    // int8 form of a matrix: fragment-major int8 values + per-output-row scales, both uploaded
+    auto packed_q8 = [&](const std::string& name, const float*& scale_dev) -> const void* {
+        const HostTensor& t = pack.get(name);
+        std::vector<float> sc;
+        auto bytes = pack_q8_weight(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), sc);
+        extra_.emplace_back(bytes.size());
+        PTTS_HIP(hipMemcpy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+        const void* wp = extra_.back().p;
+        extra_.emplace_back(sc.size() * 4);
+        PTTS_HIP(hipMemcpy(extra_.back().p, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+        scale_dev = static_cast<const float*>(extra_.back().p);
+        return wp;
+    };
     auto packed = [&](const std::string& name) -> const void* {
         const HostTensor& t = pack.get(name);
         auto bytes = pack_flow_weight(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), flow_wtype);
@@ -167,12 +183,23 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     flow_cond_packed = packed("flow.cond.w");
     for (int i = 0; i < s.lm_layers; ++i) {
         std::string p = "lm.l" + std::to_string(i) + ".";
-        lm_packed.push_back(PackedLayer{packed(p + "qkv.w"), packed(p + "out.w"), packed(p + "ff1.w"), packed(p + "ff2.w")});
+        PackedLayer pl;
+        if (q8) {
+            pl.qkv = packed_q8(p + "qkv.w", pl.s_qkv); pl.out = packed_q8(p + "out.w", pl.s_out);
+            pl.ff1 = packed_q8(p + "ff1.w", pl.s_ff1); pl.ff2 = packed_q8(p + "ff2.w", pl.s_ff2);
+        } else {
+            pl.qkv = packed(p + "qkv.w"); pl.out = packed(p + "out.w"); pl.ff1 = packed(p + "ff1.w"); pl.ff2 = packed(p + "ff2.w");
+        }
+        lm_packed.push_back(pl);
     }
     for (int i = 0; i < nb; ++i) {
         std::string p = "flow.b" + std::to_string(i) + ".";
-        flow_tabs.w_fc1.push_back(packed(p + "fc1.w"));
-        flow_tabs.w_fc2.push_back(packed(p + "fc2.w"));
+        const float *s1 = nullptr, *s2 = nullptr;
+        const bool fq8 = flow_block_wtype == W_I8;
+        flow_tabs.w_fc1.push_back(fq8 ? packed_q8(p + "fc1.w", s1) : packed(p + "fc1.w"));
+        flow_tabs.w_fc2.push_back(fq8 ? packed_q8(p + "fc2.w", s2) : packed(p + "fc2.w"));
+        flow_tabs.s_fc1.push_back(s1);
+        flow_tabs.s_fc2.push_back(s2);
         flow_tabs.b_fc1.push_back(f(p + "fc1.b"));
         flow_tabs.b_fc2.push_back(f(p + "fc2.b"));
         flow_tabs.ln_g.push_back(f(p + "ln.g"));
@@ -644,6 +671,13 @@ void Engine::lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* 
         if (b.lm_pos_host[slot0 + i] + rpb > b.lm_cap)
             throw std::runtime_error("LM context exceeds the KV-cache capacity (voice + text + frames too long)");
     b.ensure_rows(static_cast<size_t>(nb) * rpb, s.d_model, s.lm_ffn);
+    if (model_->lm_wtype == W_I8) {
+        lm_rows_q8(b, slot0, nb, rpb, X);
+        if (adv_dev) launch_advance_pos_vec(b.lm_pos.as<int>() + slot0, adv_dev, nb, b.st);
+        else launch_advance_pos(b.lm_pos.as<int>() + slot0, nb, rpb, b.st);
+        for (int i = 0; i < nb; ++i) b.lm_pos_host[slot0 + i] += adv_host ? adv_host[i] : rpb;
+        return;
+    }
     const auto& layers = hd_.lm;
     const long long layer_stride = static_cast<long long>(b.B) * b.lm_cap * s.d_model;
     transformer(layers, b.lm_k.f(), b.lm_v.f(), layer_stride, b.lm_cap, b.lm_pos.as<int>() + slot0, slot0, nb, rpb, X, s.d_model,
@@ -651,6 +685,57 @@ void Engine::lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* 
     if (adv_dev) launch_advance_pos_vec(b.lm_pos.as<int>() + slot0, adv_dev, nb, b.st);
     else launch_advance_pos(b.lm_pos.as<int>() + slot0, nb, rpb, b.st);
     for (int i = 0; i < nb; ++i) b.lm_pos_host[slot0 + i] += adv_host ? adv_host[i] : rpb;
+}
+
+// Multi-row LM pass with the int8 layer matrices: the decode step's kernels (skinny product, add & norm) over
+// M = nb * rpb rows, with the multi-row rotate/append and tiled attention in place of the one-row kernel.
+void Engine::lm_rows_q8(Batch& b, int slot0, int nb, int rpb, float* X) {
+    const Spec& s = spec();
+    const int D = s.d_model, F = s.lm_ffn, M = nb * rpb;
+    hipStream_t st = b.st;
+    if (b.pre_partial.bytes < static_cast<size_t>(M) * D * 4) {
+        PTTS_HIP(hipDeviceSynchronize());
+        b.pre_partial.alloc(static_cast<size_t>(M) * D * 4);
+    }
+    const long long layer_stride = static_cast<long long>(b.B) * b.lm_cap * D;
+    AddNormArgs an;
+    an.X = X; an.ldx = D; an.M = M; an.D = D; an.eps = s.lm_eps;
+    an.g = hd_.lm[0].ln1g; an.b = hd_.lm[0].ln1b; an.H = b.h.f();
+    launch_add_norm(an, st);
+    for (int l = 0; l < s.lm_layers; ++l) {
+        const TfLayer& w = hd_.lm[l];
+        const Model::PackedLayer& pw = model_->lm_packed[l];
+        SkinnyArgs q;
+        q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.wtype = W_I8; q.wscale = pw.s_qkv; q.M = M; q.N = 3 * D; q.K = D; q.C = b.qkv.f(); q.ldc = 3 * D;
+        launch_skinny_gemm(q, st);
+        RopeAppendArgs r;
+        r.qkv = b.qkv.f(); r.q_out = b.q.f(); r.kcache = b.lm_k.f() + l * layer_stride; r.vcache = b.lm_v.f() + l * layer_stride;
+        r.pos = b.lm_pos.as<int>() + slot0; r.slot0 = slot0; r.rpb = rpb; r.M = M; r.d = D; r.heads = s.lm_heads; r.cap = b.lm_cap;
+        r.cos_tab = model_->lm_cos; r.sin_tab = model_->lm_sin; r.tab_len = model_->lm_tab_len;
+        launch_rope_append(r, st);
+        AttentionArgs at;
+        at.q = b.q.f(); at.out = b.att.f(); at.kcache = r.kcache; at.vcache = r.vcache; at.pos = r.pos; at.slot0 = slot0; at.rpb = rpb;
+        at.M = M; at.d = D; at.heads = s.lm_heads; at.cap = b.lm_cap; at.window = 0;
+        launch_attention(at, st);
+        SkinnyArgs o;
+        o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.wtype = W_I8; o.wscale = pw.s_out; o.M = M; o.N = D; o.K = D; o.splits = 1; o.P = b.pre_partial.f();
+        launch_skinny_gemm(o, st);
+        AddNormArgs a1 = an;
+        a1.P = b.pre_partial.f(); a1.splits = 1; a1.colscale = w.ls1; a1.g = w.ln2g; a1.b = w.ln2b;
+        launch_add_norm(a1, st);
+        SkinnyArgs f1;
+        f1.A = b.h.f(); f1.lda = D; f1.Wp = pw.ff1; f1.wtype = W_I8; f1.wscale = pw.s_ff1; f1.M = M; f1.N = F; f1.K = D; f1.act = ACT_GELU;
+        f1.C = b.ff.f(); f1.ldc = F;
+        launch_skinny_gemm(f1, st);
+        SkinnyArgs f2;
+        f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.wtype = W_I8; f2.wscale = pw.s_ff2; f2.M = M; f2.N = D; f2.K = F; f2.splits = 1; f2.P = b.pre_partial.f();
+        launch_skinny_gemm(f2, st);
+        AddNormArgs a2 = an;
+        a2.P = b.pre_partial.f(); a2.splits = 1; a2.colscale = w.ls2;
+        if (l + 1 < s.lm_layers) { a2.g = hd_.lm[l + 1].ln1g; a2.b = hd_.lm[l + 1].ln1b; }
+        else { a2.g = nullptr; a2.b = nullptr; a2.H = nullptr; }
+        launch_add_norm(a2, st);
+    }
 }
 
 // K-slices for a split-K product: about 256 deep each, at most 16, dividing K into k-step multiples.
@@ -669,7 +754,7 @@ static int pick_splits(int K, int kstep) {
 void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev) {
     const Spec& s = spec();
     const int B = b.B, D = s.d_model, F = s.lm_ffn;
-    const int wt = model_->flow_wtype, kstep = wt == W_BF16 ? 32 : 16;
+    const int wt = model_->lm_wtype, kstep = wt == W_I8 ? 64 : wt == W_BF16 ? 32 : 16;
     launch_prep_latent(seq_dev, b.seq_in.f(), B, s.latent, 0, hd_.bos, nullptr, b.st);
     const DevWeight& win = hd_.lm_in;
     GemmArgs g;
@@ -687,7 +772,7 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         const TfLayer& w = hd_.lm[l];
         const Model::PackedLayer& pw = model_->lm_packed[l];
         SkinnyArgs q;
-        q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.wtype = wt; q.M = B; q.N = 3 * D; q.K = D; q.C = b.qkv.f(); q.ldc = 3 * D;
+        q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.wtype = wt; q.wscale = pw.s_qkv; q.M = B; q.N = 3 * D; q.K = D; q.C = b.qkv.f(); q.ldc = 3 * D;
         launch_skinny_gemm(q, b.st);
         AttnDecodeArgs at;
         at.qkv = b.qkv.f(); at.kcache = b.lm_k.f() + l * layer_stride; at.vcache = b.lm_v.f() + l * layer_stride;
@@ -696,17 +781,17 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         at.out = b.att.f();
         launch_attn_decode(at, b.st);
         SkinnyArgs o;
-        o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.wtype = wt; o.M = B; o.N = D; o.K = D; o.splits = s_out; o.P = b.partial.f();
+        o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.wtype = wt; o.wscale = pw.s_out; o.M = B; o.N = D; o.K = D; o.splits = s_out; o.P = b.partial.f();
         launch_skinny_gemm(o, b.st);
         AddNormArgs a1 = an;
         a1.P = b.partial.f(); a1.splits = s_out; a1.colscale = w.ls1; a1.g = w.ln2g; a1.b = w.ln2b;
         launch_add_norm(a1, b.st);
         SkinnyArgs f1;
-        f1.A = b.h.f(); f1.lda = D; f1.Wp = pw.ff1; f1.wtype = wt; f1.M = B; f1.N = F; f1.K = D; f1.act = ACT_GELU;
+        f1.A = b.h.f(); f1.lda = D; f1.Wp = pw.ff1; f1.wtype = wt; f1.wscale = pw.s_ff1; f1.M = B; f1.N = F; f1.K = D; f1.act = ACT_GELU;
         f1.C = b.ff.f(); f1.ldc = F;
         launch_skinny_gemm(f1, b.st);
         SkinnyArgs f2;
-        f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.wtype = wt; f2.M = B; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.partial.f();
+        f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.wtype = wt; f2.wscale = pw.s_ff2; f2.M = B; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.partial.f();
         launch_skinny_gemm(f2, b.st);
         AddNormArgs a2 = an;
         a2.P = b.partial.f(); a2.splits = s_ff2; a2.colscale = w.ls2;
@@ -751,6 +836,7 @@ void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long
     fa.steps = N; fa.mod_width = model_->mod_width;
     fa.w_in = model_->flow_in_packed; fa.b_in = hd_.flow_in_b; fa.w_out = model_->flow_out_packed; fa.b_out = hd_.flow_out_b;
     fa.host_tabs = &model_->flow_tabs; fa.workspace = b.flow_ws.f(); fa.wtype = model_->flow_wtype; fa.eps = s.flow_eps;
+    fa.block_wtype = model_->flow_block_wtype;
     fa.x0_step = x0_step; fa.x0_step_stride = x0_step_stride; fa.probe_a = probe_a; fa.probe_b = probe_b;
     launch_flow_head(fa, b.st);
 }

@@ -20,7 +20,7 @@
 
 namespace ptts {
 
-enum class Precision { FP32, BF16 };
+enum class Precision { FP32, BF16, INT8 };   // INT8: bf16 engine with int8 LM-layer and flow-block matrices
 
 struct DevWeight {
     const void* p = nullptr;
@@ -53,7 +53,9 @@ public:
     FlowHostTabs flow_tabs;      // per-block device pointers of the flow head (host arrays)
     const void *flow_in_packed = nullptr, *flow_out_packed = nullptr;  // fragment-major flow.in_proj.w / flow.final.lin.w
     // fragment-major copies of the weights the batched decode step streams (decode_kernels.hip)
-    struct PackedLayer { const void *qkv, *out, *ff1, *ff2; };
+    struct PackedLayer { const void *qkv, *out, *ff1, *ff2; const float *s_qkv = nullptr, *s_out = nullptr, *s_ff1 = nullptr, *s_ff2 = nullptr; };
+    int lm_wtype = W_F32;        // weight type of lm_packed (W_I8 in int8 mode)
+    int flow_block_wtype = W_F32;
     std::vector<PackedLayer> lm_packed;
     const void* flow_cond_packed = nullptr;
     int flow_wtype = W_F32;
@@ -160,6 +162,7 @@ public:
     void op_lm_step(Batch* b, const float* seq /*[B][latent]*/, float* cond /*[B][d_model]*/, float* eos /*[B]*/);
     void op_flow_euler(const float* cond, const float* x0, int B, float* x_out);
     void op_mimi_decode(Batch* b, const float* latents /*[B][n][latent]*/, int n, float* audio /*[B][n*frame]*/);
+    void q8_linear(const float* A, int M, int K, const float* W, int N, float* out);   // the int8 product kernel alone
 
     // timing hooks for the benchmark: HIP events recorded on the engine stream around named phases
     struct PhaseTimes { double lm_ms = 0, flow_ms = 0, dec_ms = 0, head_ms = 0; long lm_calls = 0, flow_calls = 0, dec_calls = 0, head_calls = 0; };
@@ -180,6 +183,7 @@ private:
     void frame_body(Batch& b, int parity);
     void ensure_frame_graph(Batch& b);
     void lm_bookkeeping(Batch& b);
+    void lm_rows_q8(Batch& b, int slot0, int nb, int rpb, float* X);
     void lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* adv_dev = nullptr, const int* adv_host = nullptr);
     void lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev);
     void flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B,
@@ -269,6 +273,7 @@ public:
     // flow scratch
     DevBuf cemb, ymod, mods, flow_ws;
     DevBuf partial;   // split-K slabs of the decode step [splits][B][d_model] f32
+    DevBuf pre_partial;   // one slab [rows][d_model] for the int8 prefill pass
     // audio out
     DevBuf audio;
     // staged inputs / outputs of a whole batch (Engine::stage / run_staged)

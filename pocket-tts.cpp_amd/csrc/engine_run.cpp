@@ -560,6 +560,22 @@ void Engine::op_flow_euler(const float* cond, const float* x0, int B, float* x_o
     PTTS_HIP(hipStreamSynchronize(stream_));
 }
 
+void Engine::q8_linear(const float* A, int M, int K, const float* W, int N, float* out) {
+    std::lock_guard<std::mutex> guard(mu_);
+    PTTS_HIP(hipSetDevice(opt_.device));
+    std::vector<float> scale;
+    auto wq = pack_q8_weight(W, N, K, scale);
+    DevBuf dA(static_cast<size_t>(M) * K * 4), dW(wq.size()), dS(scale.size() * 4), dC(static_cast<size_t>(M) * N * 4);
+    PTTS_HIP(hipMemcpyAsync(dA.p, A, dA.bytes, hipMemcpyHostToDevice, stream_));
+    PTTS_HIP(hipMemcpyAsync(dW.p, wq.data(), wq.size(), hipMemcpyHostToDevice, stream_));
+    PTTS_HIP(hipMemcpyAsync(dS.p, scale.data(), scale.size() * 4, hipMemcpyHostToDevice, stream_));
+    SkinnyArgs g;
+    g.A = dA.f(); g.lda = K; g.Wp = dW.p; g.wtype = W_I8; g.wscale = dS.f(); g.M = M; g.N = N; g.K = K; g.C = dC.f(); g.ldc = N;
+    launch_skinny_gemm(g, stream_);
+    PTTS_HIP(hipMemcpyAsync(out, dC.p, dC.bytes, hipMemcpyDeviceToHost, stream_));
+    PTTS_HIP(hipStreamSynchronize(stream_));
+}
+
 void Engine::op_mimi_decode(Batch* b, const float* latents, int n, float* audio) {
     std::lock_guard<std::mutex> guard(mu_);
     PTTS_HIP(hipSetDevice(opt_.device));

@@ -28,7 +28,8 @@ struct PocketTTS::Impl {
         ptts::EngineOptions o;
         o.pack_path = cfg.packPath.empty() ? cfg.modelsDir + "/pocket_tts.ptts" : cfg.packPath;
         if (cfg.precision == "fp32") o.precision = ptts::Precision::FP32;
-        else if (cfg.precision == "bf16" || cfg.precision == "int8") o.precision = ptts::Precision::BF16;
+        else if (cfg.precision == "bf16") o.precision = ptts::Precision::BF16;
+        else if (cfg.precision == "int8") o.precision = ptts::Precision::INT8;
         else throw std::runtime_error("unknown precision '" + cfg.precision + "' (expected int8, bf16 or fp32)");
         o.device = cfg.device;
         o.lsd_steps = cfg.lsdSteps;

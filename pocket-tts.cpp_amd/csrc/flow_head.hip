@@ -208,6 +208,7 @@ struct FlowBlockArgs {
     int first = 0, blk = 0;
     const void* w_in = nullptr; const float* b_in = nullptr;
     const void* w1 = nullptr; const float* b1 = nullptr; const void* w2 = nullptr;
+    const float* s1 = nullptr; const float* s2 = nullptr;   // int8 blocks: per-output-column scales of fc1 / fc2
     const float* ln_g = nullptr; const float* ln_b = nullptr;
     int B = 0, mod_width = 0, rpg = 16;   // rpg: utterance rows per workgroup row group (<= 16, the MFMA tile height)
     float eps = 1e-6f;
@@ -359,6 +360,213 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
     }
 }
 
+// ---- int8 residual block (v_mfma_i32_16x16x64_i8) ---------------------------------------------------------------
+// Same decomposition as flow_block_kernel.  The two matrix inputs (the modulated LayerNorm output and the SiLU
+// output) are quantised per row and per block of 64 consecutive k: s = max|a|, q = rint(a * 127 / s), d = s / 127;
+// y[n] = (sum over blocks of (float)isum * d) * wscale[n] + bias[n].  The input projection of the first block of a
+// step keeps its bf16 weights.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+__device__ __forceinline__ unsigned q8_pack4(const float4 v, float inv) {
+    const int q0 = (int)rintf(v.x * inv), q1 = (int)rintf(v.y * inv), q2 = (int)rintf(v.z * inv), q3 = (int)rintf(v.w * inv);
+    return (unsigned)(q0 & 0xff) | ((unsigned)(q1 & 0xff) << 8) | ((unsigned)(q2 & 0xff) << 16) | ((unsigned)(q3 & 0xff) << 24);
+}
+
+// maximum of |v| over the 16 consecutive lanes that hold one 64-wide block (one float4 each)
+__device__ __forceinline__ float q8_absmax16(const float4 v) {
+    float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
+    m = fmaxf(m, __shfl_xor(m, 4, 64));
+    m = fmaxf(m, __shfl_xor(m, 8, 64));
+    return m;
+}
+
+template <int C, int G>
+__global__ __launch_bounds__(kFlowThreads) void flow_block_q8_kernel(FlowBlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using RM = RowMap<C>;
+    constexpr int L = 32, NT = C / 16, NT1 = NT / G, KS = C / 64, KS2 = KS / G, CS = C / G;
+    constexpr int lda = C + 16, lda2 = CS + 16, ldx = L + 8;
+    constexpr int T1 = (NT1 + kFlowWaves - 1) / kFlowWaves, T2 = (NT + kFlowWaves - 1) / kFlowWaves;
+    static_assert(C % 256 == 0 && NT % G == 0 && KS % G == 0, "int8 flow block: flow_dim must be a multiple of 256 and split evenly");
+    float* hbuf = (float*)smem_raw;                                 // [16][C]: input-projection result, later the SiLU output slice
+    signed char* Aq = (signed char*)(hbuf + 16 * C);                // [16][lda]
+    float* dA = (float*)(Aq + 16 * lda);                            // [KS][16]
+    signed char* Sq = (signed char*)(dA + KS * 16);                 // [16][lda2]
+    float* dS = (float*)(Sq + 16 * lda2);                           // [KS2][16]
+    __bf16* X0 = (__bf16*)(dS + KS2 * 16);                          // [2][16][ldx]
+    __bf16* X1 = X0 + 16 * ldx;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x, row0 = blockIdx.y * a.rpg;
+    const int nrows = (a.B - row0) < a.rpg ? (a.B - row0) : a.rpg;
+    const int crow = (lane >> 4) * 4, ccol = lane & 15, g4 = lane >> 4;
+    const uint4* w1p = (const uint4*)a.w1 + ((long long)g * NT1 * KS) * 64 + lane;
+    const uint4* w2p = (const uint4*)a.w2 + ((long long)g * KS2) * 64 + lane;
+
+    uint4 wf1[T1][KS], wf2[T2][KS2];
+    float bias1[T1], sc1[T1], sc2[T2];
+#pragma unroll
+    for (int i = 0; i < T1; ++i) {
+        const int t = (wave + kFlowWaves * i) < NT1 ? (wave + kFlowWaves * i) : NT1 - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf1[i][ks] = w1p[((long long)t * KS + ks) * 64];
+        bias1[i] = a.b1[g * CS + t * 16 + ccol];
+        sc1[i] = a.s1[g * CS + t * 16 + ccol];
+    }
+#pragma unroll
+    for (int i = 0; i < T2; ++i) {
+        const int t = (wave + kFlowWaves * i) < NT ? (wave + kFlowWaves * i) : NT - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) wf2[i][ks] = w2p[((long long)t * KS + ks) * 64];
+        sc2[i] = a.s2[t * 16 + ccol];
+    }
+
+    float4 h[2][RM::NP];
+    if (a.first) {
+        const float* xin = a.x_in + (a.x_step ? (long long)(*a.x_step) * a.x_step_stride : 0);
+        for (int i = tid; i < 16 * L; i += kFlowThreads) {
+            const int r = i / L, c = i % L;
+            const float v = r < nrows ? xin[(long long)(row0 + r) * a.x_stride + c] : 0.f;
+            put_act<__bf16>(X0, X1, r * ldx + c, v);
+        }
+        __syncthreads();
+        uint4 wi[T2];
+        float bin[T2];
+#pragma unroll
+        for (int i = 0; i < T2; ++i) {
+            const int t = (wave + kFlowWaves * i) < NT ? (wave + kFlowWaves * i) : NT - 1;
+            wi[i] = ((const uint4*)a.w_in)[(long long)t * 64 + lane];   // L = 32: one bf16 k-step
+            bin[i] = a.b_in[t * 16 + ccol];
+        }
+#pragma unroll
+        for (int i = 0; i < T2; ++i) {
+            const int t = wave + kFlowWaves * i;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma_frag<__bf16>(X0, X1, ldx, 0, wi[i], acc, lane);
+            if (t < NT) {
+                const int c = t * 16 + ccol;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hbuf[(crow + r) * C + c] = acc[r] + bin[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int i = 0; i < RM::NP; ++i) h[rr][i] = ld4(hbuf + (2 * wave + rr) * C + RM::col(lane, i));
+    } else {
+        residual_update<C, G>(h, a.h_prev, a.part_prev, (long long)a.B * C, a.mods + (a.blk - 1) * 3 * C + 2 * C, a.mod_width, a.prev_b2,
+                              row0, nrows, wave, lane);
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int i = 0; i < RM::NP; ++i)
+                if (2 * wave + rr < nrows) *(float4*)(a.h_next + (long long)(row0 + 2 * wave + rr) * C + 4 * (lane + 64 * i)) = h[rr][i];
+    }
+    // LayerNorm + adaLN modulate of the wave's two rows, quantised into Aq / dA
+    {
+        const float* mblk = a.mods + a.blk * 3 * C;
+        float4 sh[2][RM::NP], sc[2][RM::NP], g4v[RM::NP], b4v[RM::NP];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int lr = 2 * wave + rr;
+            const long long grow = row0 + (lr < nrows ? lr : nrows - 1);
+#pragma unroll
+            for (int i = 0; i < RM::NP; ++i) {
+                sh[rr][i] = ld4(mblk + grow * a.mod_width + RM::col(lane, i));
+                sc[rr][i] = ld4(mblk + C + grow * a.mod_width + RM::col(lane, i));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RM::NP; ++i) { g4v[i] = ld4(a.ln_g + RM::col(lane, i)); b4v[i] = ld4(a.ln_b + RM::col(lane, i)); }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < RM::NP; ++i) sum += (h[rr][i].x + h[rr][i].y) + (h[rr][i].z + h[rr][i].w);
+            const float mean = wsum(sum) / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < RM::NP; ++i) {
+                const float d0 = h[rr][i].x - mean, d1 = h[rr][i].y - mean, d2 = h[rr][i].z - mean, d3 = h[rr][i].w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            const float rstd = 1.0f / sqrtf(wsum(q) / (float)C + a.eps);
+#pragma unroll
+            for (int i = 0; i < RM::NP; ++i) {
+                float4 y;
+                y.x = ((h[rr][i].x - mean) * rstd * g4v[i].x + b4v[i].x) * (1.0f + sc[rr][i].x) + sh[rr][i].x;
+                y.y = ((h[rr][i].y - mean) * rstd * g4v[i].y + b4v[i].y) * (1.0f + sc[rr][i].y) + sh[rr][i].y;
+                y.z = ((h[rr][i].z - mean) * rstd * g4v[i].z + b4v[i].z) * (1.0f + sc[rr][i].z) + sh[rr][i].z;
+                y.w = ((h[rr][i].w - mean) * rstd * g4v[i].w + b4v[i].w) * (1.0f + sc[rr][i].w) + sh[rr][i].w;
+                const float m = q8_absmax16(y);
+                const float inv = m > 0.f ? 127.0f / m : 0.f;
+                const int piece = lane + 64 * i, lr = 2 * wave + rr;
+                *(unsigned*)(Aq + lr * lda + 4 * piece) = q8_pack4(y, inv);
+                if ((lane & 15) == 0) dA[(piece >> 4) * 16 + lr] = m / 127.0f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- fc1: this workgroup's column slice, full K; SiLU output as f32 into hbuf[16][CS]
+#pragma unroll
+    for (int i = 0; i < T1; ++i) {
+        const int t = wave + kFlowWaves * i;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const i32x4 a4 = *(const i32x4*)(Aq + ccol * lda + ks * 64 + 16 * g4);
+            const i32x4 z = {0, 0, 0, 0};
+            const i32x4 ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a4, __builtin_bit_cast(i32x4, wf1[i][ks]), z, 0, 0, 0);
+            const float4 d4 = *(const float4*)(dA + ks * 16 + crow);
+            acc[0] += (float)ci[0] * d4.x; acc[1] += (float)ci[1] * d4.y; acc[2] += (float)ci[2] * d4.z; acc[3] += (float)ci[3] * d4.w;
+        }
+        if (t < NT1) {
+            const int cl = t * 16 + ccol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hbuf[(crow + r) * CS + cl] = silu_dev(acc[r] * sc1[i] + bias1[i]);
+        }
+    }
+    __syncthreads();
+    // quantise the SiLU slice into Sq / dS
+    for (int id = tid; id < 16 * (CS / 4); id += kFlowThreads) {
+        const int row = id / (CS / 4), piece = id % (CS / 4);
+        const float4 y = *(const float4*)(hbuf + row * CS + 4 * piece);
+        const float m = q8_absmax16(y);
+        const float inv = m > 0.f ? 127.0f / m : 0.f;
+        *(unsigned*)(Sq + row * lda2 + 4 * piece) = q8_pack4(y, inv);
+        if ((piece & 15) == 0) dS[(piece >> 4) * 16 + row] = m / 127.0f;
+    }
+    __syncthreads();
+
+    // ---- fc2: every output column, this workgroup's K-slice -> partial
+    float* pout = a.part_next + ((long long)g * a.B + row0) * C;
+#pragma unroll
+    for (int i = 0; i < T2; ++i) {
+        const int t = wave + kFlowWaves * i;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+            const i32x4 a4 = *(const i32x4*)(Sq + ccol * lda2 + ks * 64 + 16 * g4);
+            const i32x4 z = {0, 0, 0, 0};
+            const i32x4 ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a4, __builtin_bit_cast(i32x4, wf2[i][ks]), z, 0, 0, 0);
+            const float4 d4 = *(const float4*)(dS + ks * 16 + crow);
+            acc[0] += (float)ci[0] * d4.x; acc[1] += (float)ci[1] * d4.y; acc[2] += (float)ci[2] * d4.z; acc[3] += (float)ci[3] * d4.w;
+        }
+        if (t < NT) {
+            const int c = t * 16 + ccol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (crow + r < nrows) pout[(long long)(crow + r) * C + c] = acc[r] * sc2[i];
+        }
+    }
+}
+
 struct FlowFinalArgs {
     const float* h_prev = nullptr; const float* part_prev = nullptr;   // of the last block
     const float* mods = nullptr; const float* prev_b2 = nullptr;
@@ -483,6 +691,18 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
     auto kf = flow_final_kernel<WT, C, G, L>;
     set_lds_limit((const void*)kb, smem_block);
     set_lds_limit((const void*)kf, smem_final);
+    const bool q8 = a.block_wtype == W_I8;
+    size_t smem_q8 = 0;
+    void (*kq)(FlowBlockArgs) = nullptr;
+    if constexpr (std::is_same<WT, __bf16>::value && C % 256 == 0) {
+        if (q8) {
+            kq = flow_block_q8_kernel<C, G>;
+            smem_q8 = (size_t)16 * C * 4 + (size_t)16 * (C + 16) + (size_t)(C / 64) * 16 * 4 + (size_t)16 * (C / G + 16) + (size_t)(C / 64 / G) * 16 * 4 +
+                      (size_t)2 * 16 * (L + 8) * 2;
+            set_lds_limit((const void*)kq, smem_q8);
+        }
+    }
+    if (q8 && !kq) throw std::runtime_error("flow head: int8 blocks need bf16 in/out weights and flow_dim % 256 == 0");
     float* hb[2] = {a.workspace, a.workspace + (size_t)B * C};
     float* pb[2] = {a.workspace + (size_t)2 * B * C, a.workspace + (size_t)2 * B * C + (size_t)kMaxFlowSplit * B * C};
     const FlowHostTabs& tabs = *a.host_tabs;
@@ -501,8 +721,10 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
             fb.first = blk == 0; fb.blk = blk;
             fb.w_in = a.w_in; fb.b_in = a.b_in; fb.w1 = tabs.w_fc1[blk]; fb.b1 = tabs.b_fc1[blk]; fb.w2 = tabs.w_fc2[blk];
             fb.ln_g = tabs.ln_g[blk]; fb.ln_b = tabs.ln_b[blk];
+            if (q8) { fb.s1 = tabs.s_fc1[blk]; fb.s2 = tabs.s_fc2[blk]; }
             fb.B = B; fb.mod_width = a.mod_width; fb.eps = a.eps; fb.rpg = rpg;
-            hipLaunchKernelGGL(kb, dim3(G, RG), dim3(kFlowThreads), smem_block, s, fb);
+            if (q8) hipLaunchKernelGGL(kq, dim3(G, RG), dim3(kFlowThreads), smem_q8, s, fb);
+            else hipLaunchKernelGGL(kb, dim3(G, RG), dim3(kFlowThreads), smem_block, s, fb);
             cur ^= 1;
         }
         FlowFinalArgs ff;

@@ -11,7 +11,7 @@
 namespace ptts {
 
 enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_ELU = 3 };
-enum WType : int { W_F32 = 0, W_BF16 = 1 };
+enum WType : int { W_F32 = 0, W_BF16 = 1, W_I8 = 2 };
 
 // C[m][n] = epilogue( sum_k act_a(A[m][k]) * W[n][k] )
 //   v = acc + bias[n % bias_mod]; v = act_pre(v); v *= G[m][n]; v *= colscale[n] * alpha; v += R[m][n];
@@ -107,8 +107,9 @@ void launch_shift_history(float* buf, long long bs, int T, int H, int C, int B, 
 // as a chain of per-block launches (flow_head.hip).  mods[j][b][:] holds the precomputed adaLN vectors of
 // Euler step j (they depend on c and j only): per block (shift, scale, gate) x C, then final (shift, scale) x C.
 struct FlowHostTabs {   // host arrays of per-block device pointers
-    std::vector<const void*> w_fc1, w_fc2;           // pack_flow_weight layout, [C][C]
+    std::vector<const void*> w_fc1, w_fc2;           // pack_flow_weight (or pack_q8_weight) layout, [C][C]
     std::vector<const float*> b_fc1, b_fc2, ln_g, ln_b;
+    std::vector<const float*> s_fc1, s_fc2;          // int8 blocks: per-output-column weight scales
 };
 struct FlowHeadArgs {
     const float* x0 = nullptr;    // start points, row b at x0 + b * x0_stride (+ *x0_step * x0_step_stride if x0_step is set)
@@ -122,7 +123,8 @@ struct FlowHeadArgs {
     const void* w_out = nullptr; const float* b_out = nullptr;     // [L][C], pack_flow_weight layout
     const FlowHostTabs* host_tabs = nullptr;
     float* workspace = nullptr;   // flow_head_workspace_bytes(B, C, wtype) bytes
-    int wtype = W_F32;
+    int wtype = W_F32;            // of w_in / w_out
+    int block_wtype = -1;         // of the residual blocks' fc1 / fc2 (-1: same as wtype; W_I8: int8 blocks)
     float eps = 1e-6f;
 };
 void launch_flow_head(const FlowHeadArgs& a, hipStream_t s);
@@ -130,6 +132,9 @@ size_t flow_head_workspace_bytes(int B, int C, int wtype);
 void flow_head_prepare(int C, int wtype);   // once per device, outside stream capture
 // Host-side reorder of a flow-head weight W[N][K] into the fragment-major layout the kernel streams.
 std::vector<unsigned char> pack_flow_weight(const float* W, int N, int K, int wtype);
+// int8 form of the same layout (k-steps of 64, 16 values per lane): per output row n, scale[n] = max|W[n][:]| / 127
+// and q = rint(W * 127 / max) in [-127, 127].  K must be a multiple of 64.
+std::vector<unsigned char> pack_q8_weight(const float* W, int N, int K, std::vector<float>& scale);
 
 // ---- batched decode step (decode_kernels.hip) -----------------------------------------------------
 // C[M][N] = A[M][K] * W^T with f32 A and W fragment-major (pack_flow_weight layout, f32 or bf16).
@@ -142,6 +147,7 @@ struct SkinnyArgs {
     const float* bias = nullptr; int act = ACT_NONE;
     float* C = nullptr; int ldc = 0;
     float* P = nullptr;
+    const float* wscale = nullptr;   // W_I8: per-output-column weight scale
 };
 void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s);
 

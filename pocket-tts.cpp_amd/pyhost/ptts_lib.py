@@ -51,7 +51,7 @@ EXT_SYMBOLS = [
     "pocket_tts_stage_ids", "pocket_tts_run_staged", "pocket_tts_fetch_staged",
     "pocket_tts_tokenize", "ptts_text_conditioner", "ptts_state_new", "ptts_state_free", "ptts_state_reset",
     "ptts_lm_prefill", "ptts_lm_step", "ptts_flow_euler", "ptts_mimi_decode", "ptts_mimi_encode",
-    "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats",
+    "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_q8_linear",
     "ptts_tokenizer_new", "ptts_tokenizer_free", "ptts_tokenizer_vocab", "ptts_tokenizer_encode",
     "ptts_audio_load_wav", "ptts_audio_save_wav", "ptts_audio_resample", "ptts_audio_normalize",
 ]
@@ -111,6 +111,7 @@ def load() -> C.CDLL:
     L.ptts_phase_timing.restype = ci; L.ptts_phase_timing.argtypes = [vp, ci]
     L.ptts_phase_times.restype = ci; L.ptts_phase_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.ptts_scheduler_stats.restype = ci; L.ptts_scheduler_stats.argtypes = [vp, C.POINTER(C.c_long)]
+    L.ptts_q8_linear.restype = ci; L.ptts_q8_linear.argtypes = [vp, f32p, ci, ci, f32p, ci, f32p]
     L.ptts_weight_bytes.restype = ci; L.ptts_weight_bytes.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.ptts_tokenizer_new.restype = vp; L.ptts_tokenizer_new.argtypes = [cp]
     L.ptts_tokenizer_free.restype = None; L.ptts_tokenizer_free.argtypes = [vp]
@@ -416,6 +417,13 @@ class Engine:
         c = (C.c_long * 4)()
         _check(self.L.ptts_phase_times(self.h, t, c), "phase_times")
         return dict(lm_ms=t[0], flow_ms=t[1], dec_ms=t[2], head_ms=t[3], lm_calls=c[0], flow_calls=c[1], dec_calls=c[2], head_calls=c[3])
+
+    def q8_linear(self, A, W) -> np.ndarray:
+        A = np.ascontiguousarray(A, np.float32)
+        W = np.ascontiguousarray(W, np.float32)
+        out = np.empty((A.shape[0], W.shape[0]), np.float32)
+        _check(self.L.ptts_q8_linear(self.h, A, A.shape[0], A.shape[1], W, W.shape[0], out), "q8_linear")
+        return out
 
     def scheduler_stats(self):
         st = (C.c_long * 3)()

@@ -301,6 +301,25 @@ def bf16_model(weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     return {k: (bf16_round(v) if rounded(k) else v) for k, v in weights.items()}
 
 
+def is_int8_weight(name: str, flow_dim: int = 512) -> bool:
+    """Matrices the int8 engine holds as int8 (per-output-channel scale): LM layers and, when flow_dim is a
+    multiple of 256, the flow residual blocks."""
+    if name.startswith("lm.l") and name.endswith((".qkv.w", ".out.w", ".ff1.w", ".ff2.w")):
+        return True
+    return flow_dim % 256 == 0 and name.startswith("flow.b") and name.endswith((".fc1.w", ".fc2.w"))
+
+
+def int8_model(weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Weight set for checking the int8 engine: like bf16_model, except that the matrices the engine quantises
+    to int8 stay float32 here (both sides derive the int8 values and scales from the same float32 numbers)."""
+    q = bf16_model(weights)
+    flow_dim = weights["flow.in_proj.w"].shape[0]
+    for k, v in weights.items():
+        if is_int8_weight(k, flow_dim):
+            q[k] = v
+    return q
+
+
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser(description="write a seeded synthetic Pocket TTS weight pack")

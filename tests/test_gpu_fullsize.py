@@ -26,11 +26,13 @@ def full(tmp_path_factory, oracle_mod):
     w = pp.make_pack(path, spec, seed=1234, eos_bias=-20.0)
     path_q = str(d / "full_bf16w.ptts")
     pp.write_pack(path_q, spec, pp.bf16_model(w))
+    path_i8 = str(d / "full_int8w.ptts")
+    pp.write_pack(path_i8, spec, pp.int8_model(w))
     rng = np.random.default_rng(77)
     ids = [rng.integers(0, spec.vocab, t).astype(np.int64) for t in (32, 11, 20)]
     voices = [(rng.standard_normal((v, spec.d_model)) * 0.5).astype(np.float32) for v in (62, 30, 45)]
     return dict(lib=ptts_lib, spec=spec, path=path, path_q=path_q, ids=ids, voices=voices,
-                o=oracle_mod.Oracle(path), oq=oracle_mod.Oracle(path_q))
+                o=oracle_mod.Oracle(path), oq=oracle_mod.Oracle(path_q), oi8=oracle_mod.Oracle(path_i8, int8=True))
 
 
 def _note(line):
@@ -75,6 +77,82 @@ def test_full_bf16_offline_parity(full):
     assert worst_q <= 2e-2, worst_q
     assert worst_f <= 5e-2, worst_f
     assert snr_q >= 30.0
+    eng.close()
+
+
+def test_full_int8_graphs_and_offline_parity(full):
+    """int8 engine (int8 LM-layer and flow-block matrices on v_mfma_i32, block-quantised activations) against the
+    oracle running the same quantisation scheme on the same weights: graph by graph, then per frame."""
+    eng = full["lib"].Engine(full["path"], precision="int8", temperature=0.0, lsd_steps=10, max_frames=F)
+    o8, spec = full["oi8"], full["spec"]
+    rng = np.random.default_rng(5)
+    # flow head alone
+    cond = rng.standard_normal((3, spec.d_model)).astype(np.float32)
+    x0 = (rng.standard_normal((3, spec.latent_dim)) * 0.8).astype(np.float32)
+    got = eng.flow_euler(cond, x0)
+    want = np.stack([o8.flow_euler(cond[i], x0[i], 10) for i in range(3)])
+    e_flow = float(np.abs(got - want).max())
+    # LM: prefill + 3 decode steps on two slots
+    st = eng.state(2)
+    ost = [o8.lm_state(128), o8.lm_state(128)]
+    e_lm = 0.0
+    for slot in range(2):
+        emb = (rng.standard_normal((20 + 7 * slot, spec.d_model)) * 0.5).astype(np.float32)
+        eng.lm_prefill(st, slot, emb)
+        o8.lm_main(ost[slot], None, emb)
+    seq = np.full((2, spec.latent_dim), np.nan, np.float32)
+    for _ in range(3):
+        c, e = eng.lm_step(st, seq)
+        for slot in range(2):
+            oc, oe = o8.lm_main(ost[slot], seq[slot:slot + 1], None)
+            e_lm = max(e_lm, float(np.abs(c[slot] - oc).max()), abs(float(e[slot]) - float(oe)))
+        seq = (rng.standard_normal((2, spec.latent_dim)) * 0.7).astype(np.float32)
+    # whole path, teacher-forced
+    res = eng.generate_ids(full["ids"], full["voices"])
+    worst = worst_f = 0.0
+    for i in range(3):
+        lat8, _, frames = oracle_replay(o8, full["ids"][i], full["voices"][i], res[i]["latents"], 10, F)
+        latf, _, _ = oracle_replay(full["o"], full["ids"][i], full["voices"][i], res[i]["latents"], 10, F)
+        assert res[i]["frames"] == frames == F
+        worst = max(worst, float(np.abs(res[i]["latents"] - lat8).max()))
+        worst_f = max(worst_f, float(np.abs(res[i]["latents"] - latf).max()))
+    _note(f"int8 full size: flow head max-abs {e_flow:.3e}, LM cond/eos max-abs {e_lm:.3e}, per-frame latent max-abs vs int8 oracle "
+          f"{worst:.3e}, vs f32 oracle {worst_f:.3e}")
+    # Dynamic activation quantisation is discontinuous: the int8 ORACLE moves by ~4e-2 (LM conditioning, magnitude
+    # ~3.5) and ~1e-2 (flow head) when its inputs are perturbed by 1e-6, because a handful of roundings flip.  Two
+    # correct implementations therefore agree only to that noise floor; the kernel arithmetic itself is checked
+    # exactly in test_int8_product_is_exact.  Bounds: a few times the floor, and never further from the int8 oracle
+    # than int8 is from float.
+    assert e_flow <= 5e-2 and e_lm <= 1.5e-1
+    assert worst <= 1.5 * worst_f and worst <= 3e-1
+    eng.close()
+
+
+def test_int8_product_is_exact(full):
+    """The int8 kernel against a numpy restatement of the scheme on identical inputs: every rounding decision is
+    then the same, the block sums are integers, and only the float32 scaling differs in its last bits."""
+    eng = full["lib"].Engine(full["path"], precision="int8", temperature=0.0, lsd_steps=1, max_frames=1)
+    rng = np.random.default_rng(11)
+    for (M, K, N) in [(64, 1024, 3072), (5, 256, 64), (70, 4096, 1024)]:
+        A = (rng.standard_normal((M, K)) * rng.uniform(0.1, 3.0, (M, 1))).astype(np.float32)
+        A[0, :64] = 0.0                                            # an all-zero block
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        mw = np.abs(W).max(axis=1)
+        invw = np.where(mw > 0, np.float32(127.0) / mw, 0).astype(np.float32)
+        qw = np.clip(np.rint(W * invw[:, None]), -127, 127).astype(np.int32)
+        sw = (mw / np.float32(127.0)).astype(np.float32)
+        Ab = A.reshape(M, K // 64, 64)
+        ma = np.abs(Ab).max(axis=2)
+        inva = np.where(ma > 0, np.float32(127.0) / np.where(ma > 0, ma, 1), 0).astype(np.float32)
+        qa = np.clip(np.rint(Ab * inva[:, :, None]), -127, 127).astype(np.int32)
+        da = (ma / np.float32(127.0)).astype(np.float32)
+        acc = np.zeros((M, N), np.float32)
+        for kb in range(K // 64):
+            isum = qa[:, kb, :] @ qw[:, kb * 64:(kb + 1) * 64].T
+            acc = (acc + isum.astype(np.float32) * da[:, kb:kb + 1]).astype(np.float32)
+        want = acc * sw[None, :]
+        got = eng.q8_linear(A, W)
+        assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), (M, K, N)
     eng.close()
 
 
