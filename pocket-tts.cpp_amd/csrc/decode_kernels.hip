@@ -171,10 +171,12 @@ __device__ __forceinline__ unsigned quantize4(const float4 v, float inv) {
 
 __device__ __forceinline__ float block_absmax16(const float4 v) {
     float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    m = fmaxf(m, __shfl_xor(m, 1, 64));
-    m = fmaxf(m, __shfl_xor(m, 2, 64));
-    m = fmaxf(m, __shfl_xor(m, 4, 64));
-    m = fmaxf(m, __shfl_xor(m, 8, 64));
+    // 16-lane (one DPP row) maximum without touching LDS: swap within pairs, swap pairs within quads, mirror each
+    // half row, mirror the row; after each step every lane holds the maximum of a group twice as large
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, true)));
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, true)));
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x141, 0xF, 0xF, true)));
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x140, 0xF, 0xF, true)));
     return m;
 }
 

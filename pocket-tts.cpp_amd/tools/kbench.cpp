@@ -86,6 +86,23 @@ static void bench_skinny(const char* name, int M, int N, int K, int splits) {
     time_it(name, 300, [&](hipStream_t s) { launch_skinny_gemm(a, s); }, (double)N * K * 2 + (double)M * K * 4 + (double)M * N * 4 * splits, 2.0 * M * N * K);
 }
 
+static void bench_skinny_q8(const char* name, int M, int N, int K, int splits) {
+    auto w = rnd((size_t)N * K);
+    std::vector<float> sc;
+    auto bytes = pack_q8_weight(w.data(), N, K, sc);
+    void* wp = nullptr;
+    CK(hipMalloc(&wp, bytes.size()));
+    CK(hipMemcpy(wp, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    float* sp = (float*)dalloc(sc.size() * 4);
+    SkinnyArgs a;
+    a.A = (const float*)dalloc((size_t)M * K * 4); a.lda = K;
+    a.Wp = wp; a.wtype = W_I8; a.wscale = sp;
+    a.M = M; a.N = N; a.K = K; a.splits = splits;
+    if (splits > 1) a.P = (float*)dalloc((size_t)splits * M * N * 4, 0);
+    else { a.C = (float*)dalloc((size_t)M * N * 4, 0); a.ldc = N; }
+    time_it(name, 300, [&](hipStream_t s) { launch_skinny_gemm(a, s); }, (double)N * K + (double)M * K * 4 + (double)M * N * 4 * splits, 2.0 * M * N * K);
+}
+
 static void bench_gemm(const char* name, int M, int N, int K, int split_a, int lda = 0) {
     GemmArgs g;
     if (!lda) lda = K;
@@ -131,6 +148,8 @@ int main(int argc, char** argv) {
     if (want("skinny_ff1")) bench_skinny("skinny_ff1", 64, 4096, 1024, 1);
     if (want("skinny_out")) bench_skinny("skinny_out", 64, 1024, 1024, 4);
     if (want("skinny_ff2")) bench_skinny("skinny_ff2", 64, 1024, 4096, 16);
+    if (want("skinny_q8_qkv")) bench_skinny_q8("skinny_q8_qkv", 64, 3072, 1024, 1);
+    if (want("skinny_q8_ff2")) bench_skinny_q8("skinny_q8_ff2", 64, 1024, 4096, 16);
     if (want("gemm_ada")) bench_gemm("gemm_ada", 640, 10240, 512, 1);
     if (want("gemm_dec_qkv")) bench_gemm("gemm_dec_qkv", 15360, 1536, 512, 0);
     if (want("gemm_dec_ff2")) bench_gemm("gemm_dec_ff2", 15360, 512, 2048, 0);

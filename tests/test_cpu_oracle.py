@@ -105,6 +105,29 @@ def test_oracle_stop_rule_and_chunking(packs, oracle_mod):
     assert hit, "no trial crossed the EOS threshold: the tiny_eos pack no longer exercises the stop rule"
 
 
+def test_oracle_int8_mode_is_quantisation_noise_away(packs, oracle_mod):
+    """int8 mode (LM-layer matrices int8, activations quantised per 64-wide block): close to, but not equal to, the
+    float model; and switching it on for one oracle object leaves another object on the same pack untouched."""
+    path, spec, _ = packs["tiny"]
+    of, o8 = oracle_mod.Oracle(path), oracle_mod.Oracle(path, int8=True)
+    rng = np.random.default_rng(9)
+    emb = (rng.standard_normal((6, spec.d_model)) * 0.5).astype(np.float32)
+    seq = np.full((1, spec.latent_dim), np.nan, np.float32)
+
+    def cond_of(o):
+        st = o.lm_state(32)
+        o.lm_main(st, None, emb)
+        return o.lm_main(st, seq, None)[0]
+
+    cf, c8 = cond_of(of), cond_of(o8)
+    d = np.abs(cf - c8).max()
+    assert 1e-4 < d < 0.05 * np.abs(cf).max() + 0.05
+    o8.close()
+    np.testing.assert_array_equal(cond_of(of), cf)   # the registry entry of the closed object is gone
+    of2 = oracle_mod.Oracle(path)
+    np.testing.assert_array_equal(cond_of(of2), cf)
+
+
 # ----------------------------------------------------------------------------- multi-rank host logic
 
 def test_partition_is_balanced_and_deterministic():
