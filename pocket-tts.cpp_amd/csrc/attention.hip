@@ -23,6 +23,9 @@ constexpr int kKB = 64;        // keys per staged block
 constexpr int kKStride = 68;   // floats per K row in LDS (16-byte aligned rows, 4-bank skew)
 constexpr int kVStride = 66;   // floats per V row in LDS (read as scalars)
 
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+
+template <bool KV16>
 __global__ __launch_bounds__(256) void attention_tile_kernel(AttentionArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[kKB * kKStride];
     __shared__ __attribute__((aligned(16))) float Vs[kKB * kVStride];
@@ -54,8 +57,6 @@ __global__ __launch_bounds__(256) void attention_tile_kernel(AttentionArgs a) {
     int k_lo = 0;
     if (a.window > 0 && pos0 + t_wg - a.window + 1 > 0) k_lo = pos0 + t_wg - a.window + 1;
     const long long cbase = (long long)(a.slot0 + b) * a.cap * a.d + h * 64;
-    const float* kc = a.kcache + cbase;
-    const float* vc = a.vcache + cbase;
 
     // staging assignment: thread -> key rows (tid / 16) + 16 r, dims 4 * (tid % 16) .. +3
     const int s_key = tid >> 4, s_dim = 4 * (tid & 15);
@@ -65,9 +66,15 @@ __global__ __launch_bounds__(256) void attention_tile_kernel(AttentionArgs a) {
         for (int r = 0; r < 4; ++r) {
             int key = kb + s_key + 16 * r;
             if (key > p_hi) key = p_hi;
-            const long long off = (long long)(key % a.cap) * a.d + s_dim;
-            kreg[r] = *(const float4*)(kc + off);
-            vreg[r] = *(const float4*)(vc + off);
+            const long long off = cbase + (long long)(key % a.cap) * a.d + s_dim;
+            if constexpr (KV16) {
+                const bf16x4_t k4b = *(const bf16x4_t*)((const __bf16*)a.kcache + off), v4b = *(const bf16x4_t*)((const __bf16*)a.vcache + off);
+                kreg[r] = make_float4((float)k4b[0], (float)k4b[1], (float)k4b[2], (float)k4b[3]);
+                vreg[r] = make_float4((float)v4b[0], (float)v4b[1], (float)v4b[2], (float)v4b[3]);
+            } else {
+                kreg[r] = *(const float4*)((const float*)a.kcache + off);
+                vreg[r] = *(const float4*)((const float*)a.vcache + off);
+            }
         }
     };
     auto store_block = [&]() {
@@ -154,7 +161,8 @@ void launch_attention_tiled(const AttentionArgs& a, hipStream_t s) {
     if (a.d != a.heads * 64) throw std::runtime_error("attention: head dimension must be 64");
     if (a.rpb <= 0 || a.M % a.rpb) throw std::runtime_error("attention: rows must be a whole number of slots");
     dim3 grid((a.rpb + 63) / 64, a.heads, a.M / a.rpb), block(256);
-    hipLaunchKernelGGL(attention_tile_kernel, grid, block, 0, s, a);
+    if (a.kv16) hipLaunchKernelGGL(attention_tile_kernel<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(attention_tile_kernel<false>, grid, block, 0, s, a);
 }
 
 }  // namespace ptts

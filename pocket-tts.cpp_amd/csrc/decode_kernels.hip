@@ -383,6 +383,7 @@ void launch_add_norm(const AddNormArgs& a, hipStream_t s) {
 // softmax over its range (lane per key for the scores, then 4 key groups x 16 channel quads for P.V) and
 // leaves (max, sum, unnormalised output) in LDS; wave 0 merges the four and adds the new token, whose
 // rotated key and value never leave registers.  Every wave rotates q itself; wave 0 appends k, v to the cache.
+template <bool KV16>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -391,15 +392,20 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     const int pc = p < a.tab_len ? p : a.tab_len - 1;
     const float cs = a.cos_tab[(long long)pc * 32 + (lane >> 1)], sn = a.sin_tab[(long long)pc * 32 + (lane >> 1)];
     const float* row = a.qkv + (long long)m * 3 * a.d + h * 64;
-    const float qv = row[lane], kv = row[a.d + lane], vv = row[2 * a.d + lane];
+    float qv = row[lane], kv = row[a.d + lane], vv = row[2 * a.d + lane];
+    for (int s = 1; s < a.qkv_splits; ++s) {
+        const float* rs = row + (long long)s * a.M * 3 * a.d;
+        qv += rs[lane]; kv += rs[a.d + lane]; vv += rs[2 * a.d + lane];
+    }
     const float qo = __shfl_xor(qv, 1, 64), ko = __shfl_xor(kv, 1, 64);
     // pair (2i, 2i+1): even lane x*c - y*s, odd lane x*s + y*c, with x the even and y the odd element
     const float qr = (lane & 1) ? (qo * sn + qv * cs) : (qv * cs - qo * sn);
     const float kr = (lane & 1) ? (ko * sn + kv * cs) : (kv * cs - ko * sn);
     const long long cbase = (long long)(a.slot0 + m) * a.cap * a.d + h * 64;
     if (w == 0) {
-        a.kcache[cbase + (long long)(p % a.cap) * a.d + lane] = kr;
-        a.vcache[cbase + (long long)(p % a.cap) * a.d + lane] = vv;
+        const long long at = cbase + (long long)(p % a.cap) * a.d + lane;
+        if constexpr (KV16) { ((__bf16*)a.kcache)[at] = (__bf16)kr; ((__bf16*)a.vcache)[at] = (__bf16)vv; }
+        else { ((float*)a.kcache)[at] = kr; ((float*)a.vcache)[at] = vv; }
     }
     int j0 = 0;
     if (a.window > 0 && p - a.window + 1 > 0) j0 = p - a.window + 1;
@@ -416,16 +422,31 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     float4 q[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) q[i] = *(const float4*)(qs + 4 * i);
-    const float* kc = a.kcache + cbase;
-    const float* vc = a.vcache + cbase;
+    auto ld4 = [&](const void* base, long long idx) -> float4 {
+        if constexpr (KV16) {
+            const bf16x4 v = *(const bf16x4*)((const __bf16*)base + idx);
+            return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+        } else {
+            return *(const float4*)((const float*)base + idx);
+        }
+    };
     float mx = -INFINITY;
     for (int j = lane; j < cnt; j += 64) {
-        const float* kr_ = kc + (long long)((j0 + kb + j) % a.cap) * a.d;
+        const long long kr_ = cbase + (long long)((j0 + kb + j) % a.cap) * a.d;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if constexpr (KV16) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float4 k4 = *(const float4*)(kr_ + 4 * i);
-            s0 += q[i].x * k4.x; s1 += q[i].y * k4.y; s2 += q[i].z * k4.z; s3 += q[i].w * k4.w;
+            for (int i = 0; i < 8; ++i) {
+                const bf16x8 k8 = *(const bf16x8*)((const __bf16*)a.kcache + kr_ + 8 * i);
+                s0 += q[2 * i].x * (float)k8[0]; s1 += q[2 * i].y * (float)k8[1]; s2 += q[2 * i].z * (float)k8[2]; s3 += q[2 * i].w * (float)k8[3];
+                s0 += q[2 * i + 1].x * (float)k8[4]; s1 += q[2 * i + 1].y * (float)k8[5]; s2 += q[2 * i + 1].z * (float)k8[6]; s3 += q[2 * i + 1].w * (float)k8[7];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float4 k4 = *(const float4*)((const float*)a.kcache + kr_ + 4 * i);
+                s0 += q[i].x * k4.x; s1 += q[i].y * k4.y; s2 += q[i].z * k4.z; s3 += q[i].w * k4.w;
+            }
         }
         const float sv = ((s0 + s1) + (s2 + s3)) * 0.125f;
         sc[j] = sv;
@@ -446,10 +467,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     int j = kg;
     for (; j + 12 < cnt; j += 16) {
-        const float4 v0 = *(const float4*)(vc + (long long)((j0 + kb + j) % a.cap) * a.d + 4 * cq);
-        const float4 v1 = *(const float4*)(vc + (long long)((j0 + kb + j + 4) % a.cap) * a.d + 4 * cq);
-        const float4 v2 = *(const float4*)(vc + (long long)((j0 + kb + j + 8) % a.cap) * a.d + 4 * cq);
-        const float4 v3 = *(const float4*)(vc + (long long)((j0 + kb + j + 12) % a.cap) * a.d + 4 * cq);
+        const float4 v0 = ld4(a.vcache, cbase + (long long)((j0 + kb + j) % a.cap) * a.d + 4 * cq);
+        const float4 v1 = ld4(a.vcache, cbase + (long long)((j0 + kb + j + 4) % a.cap) * a.d + 4 * cq);
+        const float4 v2 = ld4(a.vcache, cbase + (long long)((j0 + kb + j + 8) % a.cap) * a.d + 4 * cq);
+        const float4 v3 = ld4(a.vcache, cbase + (long long)((j0 + kb + j + 12) % a.cap) * a.d + 4 * cq);
         const float p0 = sc[j], p1 = sc[j + 4], p2 = sc[j + 8], p3 = sc[j + 12];
         o.x += (p0 * v0.x + p1 * v1.x) + (p2 * v2.x + p3 * v3.x);
         o.y += (p0 * v0.y + p1 * v1.y) + (p2 * v2.y + p3 * v3.y);
@@ -457,7 +478,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
         o.w += (p0 * v0.w + p1 * v1.w) + (p2 * v2.w + p3 * v3.w);
     }
     for (; j < cnt; j += 4) {
-        const float4 v0 = *(const float4*)(vc + (long long)((j0 + kb + j) % a.cap) * a.d + 4 * cq);
+        const float4 v0 = ld4(a.vcache, cbase + (long long)((j0 + kb + j) % a.cap) * a.d + 4 * cq);
         const float p0 = sc[j];
         o.x += p0 * v0.x; o.y += p0 * v0.y; o.z += p0 * v0.z; o.w += p0 * v0.w;
     }
@@ -492,7 +513,8 @@ void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     const size_t smem = ((size_t)4 * (64 + scap) + 4 * 68) * sizeof(float);
     if (smem > 64 * 1024) throw std::runtime_error("attention: context capacity too large for the LDS score buffer");
     dim3 grid((unsigned)(a.M * a.heads)), block(256);
-    hipLaunchKernelGGL(attn_decode_kernel, grid, block, smem, s, a);
+    if (a.kv16) hipLaunchKernelGGL(attn_decode_kernel<true>, grid, block, smem, s, a);
+    else hipLaunchKernelGGL(attn_decode_kernel<false>, grid, block, smem, s, a);
 }
 
 }  // namespace ptts

@@ -304,12 +304,15 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     dec_cap = s.mimi_context + kDecChunk * U + 8;
     const int T0 = kDecChunk * U;
     max_rows = std::max(std::max(B, 256), B * T0);
-    lm_k.alloc(static_cast<size_t>(s.lm_layers) * B * lm_cap * D * 4);
-    lm_v.alloc(static_cast<size_t>(s.lm_layers) * B * lm_cap * D * 4);
+    // bf16 and int8 engines keep K and V in bf16 (half the cache traffic of the decode step); fp32 keeps f32
+    kv16 = e.model().flow_wtype == W_BF16 && std::getenv("POCKET_TTS_KV_F32") == nullptr ? 1 : 0;
+    const size_t kvb = kv16 ? 2 : 4;
+    lm_k.alloc(static_cast<size_t>(s.lm_layers) * B * lm_cap * D * kvb);
+    lm_v.alloc(static_cast<size_t>(s.lm_layers) * B * lm_cap * D * kvb);
     lm_pos.alloc(static_cast<size_t>(B) * 4);
     lm_pos_host.assign(B, 0);
-    dec_k.alloc(static_cast<size_t>(s.mimi_layers) * B * dec_cap * M * 4);
-    dec_v.alloc(static_cast<size_t>(s.mimi_layers) * B * dec_cap * M * 4);
+    dec_k.alloc(static_cast<size_t>(s.mimi_layers) * B * dec_cap * M * kvb);
+    dec_v.alloc(static_cast<size_t>(s.mimi_layers) * B * dec_cap * M * kvb);
     dec_pos.alloc(static_cast<size_t>(B) * 4);
     const int dmax = std::max(D, M), fmax = std::max(s.lm_ffn, s.mimi_ffn);
     // transformer scratch: LM passes use at most max(B, 256) rows of width D, decoder passes B*T0 rows of width M
@@ -619,7 +622,7 @@ Batch* Engine::acquire_batch(int B, int lane) {
 // per-slot KV cache.  If last_out is given, the final residual sum is written there (batched-row
 // mapping) instead of X, which is how the decoder hands its result to the first SEANet convolution's
 // history buffer without a copy.
-void Engine::transformer(const std::vector<TfLayer>& layers, float* kc, float* vc, long long layer_stride, int cap,
+void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc, int kv16, long long layer_stride, int cap,
                          const int* pos_dev, int slot0, int nb, int rpb, float* X, int d, int heads, int ffn, float eps,
                          int window, const float* cos_tab, const float* sin_tab, int tab_len, const TfScratch& b, float* last_out,
                          long long last_bs, int last_ld, hipStream_t st, bool split_a) {
@@ -634,12 +637,13 @@ void Engine::transformer(const std::vector<TfLayer>& layers, float* kc, float* v
         g.split_a = split_a;
         launch_gemm(g, st);
         RopeAppendArgs r;
-        r.qkv = b.qkv; r.q_out = b.q; r.kcache = kc + l * layer_stride; r.vcache = vc + l * layer_stride;
+        const long long kv_off = static_cast<long long>(l) * layer_stride * (kv16 ? 2 : 4);
+        r.qkv = b.qkv; r.q_out = b.q; r.kcache = static_cast<char*>(kc) + kv_off; r.vcache = static_cast<char*>(vc) + kv_off; r.kv16 = kv16;
         r.pos = pos_dev; r.slot0 = slot0; r.rpb = rpb; r.M = M; r.d = d; r.heads = heads; r.cap = cap;
         r.cos_tab = cos_tab; r.sin_tab = sin_tab; r.tab_len = tab_len;
         launch_rope_append(r, st);
         AttentionArgs at;
-        at.q = b.q; at.out = b.att; at.kcache = r.kcache; at.vcache = r.vcache; at.pos = pos_dev; at.slot0 = slot0; at.rpb = rpb;
+        at.q = b.q; at.out = b.att; at.kcache = r.kcache; at.vcache = r.vcache; at.kv16 = kv16; at.pos = pos_dev; at.slot0 = slot0; at.rpb = rpb;
         at.M = M; at.d = d; at.heads = heads; at.cap = cap; at.window = window;
         launch_attention(at, st);
         GemmArgs o;
@@ -680,7 +684,7 @@ void Engine::lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* 
     }
     const auto& layers = hd_.lm;
     const long long layer_stride = static_cast<long long>(b.B) * b.lm_cap * s.d_model;
-    transformer(layers, b.lm_k.f(), b.lm_v.f(), layer_stride, b.lm_cap, b.lm_pos.as<int>() + slot0, slot0, nb, rpb, X, s.d_model,
+    transformer(layers, b.lm_k.p, b.lm_v.p, b.kv16, layer_stride, b.lm_cap, b.lm_pos.as<int>() + slot0, slot0, nb, rpb, X, s.d_model,
                 s.lm_heads, s.lm_ffn, s.lm_eps, 0, model_->lm_cos, model_->lm_sin, model_->lm_tab_len, b.scratch(), nullptr, 0, 0, b.st, true);
     if (adv_dev) launch_advance_pos_vec(b.lm_pos.as<int>() + slot0, adv_dev, nb, b.st);
     else launch_advance_pos(b.lm_pos.as<int>() + slot0, nb, rpb, b.st);
@@ -709,12 +713,13 @@ void Engine::lm_rows_q8(Batch& b, int slot0, int nb, int rpb, float* X) {
         q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.wtype = W_I8; q.wscale = pw.s_qkv; q.M = M; q.N = 3 * D; q.K = D; q.C = b.qkv.f(); q.ldc = 3 * D;
         launch_skinny_gemm(q, st);
         RopeAppendArgs r;
-        r.qkv = b.qkv.f(); r.q_out = b.q.f(); r.kcache = b.lm_k.f() + l * layer_stride; r.vcache = b.lm_v.f() + l * layer_stride;
+        const long long kv_off = static_cast<long long>(l) * layer_stride * (b.kv16 ? 2 : 4);
+        r.qkv = b.qkv.f(); r.q_out = b.q.f(); r.kcache = static_cast<char*>(b.lm_k.p) + kv_off; r.vcache = static_cast<char*>(b.lm_v.p) + kv_off; r.kv16 = b.kv16;
         r.pos = b.lm_pos.as<int>() + slot0; r.slot0 = slot0; r.rpb = rpb; r.M = M; r.d = D; r.heads = s.lm_heads; r.cap = b.lm_cap;
         r.cos_tab = model_->lm_cos; r.sin_tab = model_->lm_sin; r.tab_len = model_->lm_tab_len;
         launch_rope_append(r, st);
         AttentionArgs at;
-        at.q = b.q.f(); at.out = b.att.f(); at.kcache = r.kcache; at.vcache = r.vcache; at.pos = r.pos; at.slot0 = slot0; at.rpb = rpb;
+        at.q = b.q.f(); at.out = b.att.f(); at.kcache = r.kcache; at.vcache = r.vcache; at.kv16 = b.kv16; at.pos = r.pos; at.slot0 = slot0; at.rpb = rpb;
         at.M = M; at.d = D; at.heads = s.lm_heads; at.cap = b.lm_cap; at.window = 0;
         launch_attention(at, st);
         SkinnyArgs o;
@@ -762,6 +767,11 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
     g.M = B; g.N = D; g.K = s.latent; g.split_a = 1;
     launch_gemm(g, b.st);
     const int s_out = pick_splits(D, kstep), s_ff2 = pick_splits(F, kstep);
+    int s_qkv = 1;
+    if (const char* e = std::getenv("POCKET_TTS_QKV_SPLITS")) s_qkv = std::atoi(e);
+    else if (B <= 64 && D % (4 * kstep) == 0) s_qkv = 4;   // measured at B = 64: 1 -> 0.568 ms per step, 2 -> 0.528, 4 -> 0.518
+    if (s_qkv < 1 || D % s_qkv || (D / s_qkv) % kstep) s_qkv = 1;
+    if (b.qkv.bytes < static_cast<size_t>(s_qkv) * B * 3 * D * 4) throw std::runtime_error("QKV slab buffer too small");
     if (b.partial.bytes < static_cast<size_t>(std::max(s_out, s_ff2)) * B * D * 4) throw std::runtime_error("split-K slab buffer too small");
     AddNormArgs an;
     an.X = b.x.f(); an.ldx = D; an.M = B; an.D = D; an.eps = s.lm_eps;
@@ -772,10 +782,12 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         const TfLayer& w = hd_.lm[l];
         const Model::PackedLayer& pw = model_->lm_packed[l];
         SkinnyArgs q;
-        q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.wtype = wt; q.wscale = pw.s_qkv; q.M = B; q.N = 3 * D; q.K = D; q.C = b.qkv.f(); q.ldc = 3 * D;
+        q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.wtype = wt; q.wscale = pw.s_qkv; q.M = B; q.N = 3 * D; q.K = D;
+        q.splits = s_qkv; q.P = b.qkv.f();   // K-slice slabs, summed where the attention kernel reads them
         launch_skinny_gemm(q, b.st);
         AttnDecodeArgs at;
-        at.qkv = b.qkv.f(); at.kcache = b.lm_k.f() + l * layer_stride; at.vcache = b.lm_v.f() + l * layer_stride;
+        const long long kv_off = static_cast<long long>(l) * layer_stride * (b.kv16 ? 2 : 4);
+        at.qkv = b.qkv.f(); at.qkv_splits = s_qkv; at.kcache = static_cast<char*>(b.lm_k.p) + kv_off; at.vcache = static_cast<char*>(b.lm_v.p) + kv_off; at.kv16 = b.kv16;
         at.pos = b.lm_pos.as<int>(); at.M = B; at.d = D; at.heads = s.lm_heads; at.cap = b.lm_cap; at.window = 0;
         at.cos_tab = model_->lm_cos; at.sin_tab = model_->lm_sin; at.tab_len = model_->lm_tab_len;
         at.out = b.att.f();
@@ -864,7 +876,7 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
     const int H0 = s.kernel - 1;
     const auto& layers = hd_.dec;
     const long long ybs = static_cast<long long>(H0 + T0max) * M;
-    transformer(layers, b.dec_k.f(), b.dec_v.f(), static_cast<long long>(B) * b.dec_cap * M, b.dec_cap, b.dec_pos.as<int>(), 0, B, T0,
+    transformer(layers, b.dec_k.p, b.dec_v.p, b.kv16, static_cast<long long>(B) * b.dec_cap * M, b.dec_cap, b.dec_pos.as<int>(), 0, B, T0,
                 b.dx.f(), M, s.mimi_heads, s.mimi_ffn, s.mimi_eps, s.mimi_context, model_->mimi_cos, model_->mimi_sin,
                 model_->mimi_tab_len, b.dec_scratch(), b.ybuf.f() + static_cast<long long>(H0) * M, ybs, M, st);
     // SEANet decoder

@@ -173,7 +173,7 @@ public:
 
 private:
     friend class Batch;
-    void transformer(const std::vector<TfLayer>& layers, float* kc, float* vc, long long layer_stride, int cap,
+    void transformer(const std::vector<TfLayer>& layers, void* kc, void* vc, int kv16, long long layer_stride, int cap,
                      const int* pos_dev, int slot0, int nb, int rpb, float* X, int d, int heads, int ffn, float eps,
                      int window, const float* cos_tab, const float* sin_tab, int tab_len, const TfScratch& scratch,
                      float* last_out, long long last_bs, int last_ld, hipStream_t st, bool split_a = false);
@@ -251,6 +251,7 @@ public:
     int dec_cap;      // ring capacity of the decoder transformer cache
     int max_rows;     // scratch rows for transformer passes
     // LM state
+    int kv16 = 0;           // 1: K/V caches hold bf16 (bf16 and int8 engines), 0: f32
     DevBuf lm_k, lm_v;      // [layers][B][lm_cap][d_model]
     DevBuf lm_pos;          // int[B]
     std::vector<int> lm_pos_host;

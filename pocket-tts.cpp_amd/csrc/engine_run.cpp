@@ -499,7 +499,7 @@ std::vector<float> Engine::encode_voice(const float* audio, int S) {
     TfScratch sc{sh.f(), sqkv.f(), sq.f(), satt.f(), sff.f()};
     DevBuf yd = zeros(static_cast<size_t>(U + Tpad) * M);
     if (T > model_->mimi_tab_len) throw std::runtime_error("voice clip exceeds the rotary table");
-    transformer(hd_.enc, kc.f(), vc.f(), static_cast<long long>(T) * M, T, pos.as<int>(), 0, 1, T, y.f(), M, s.mimi_heads, s.mimi_ffn,
+    transformer(hd_.enc, kc.p, vc.p, 0, static_cast<long long>(T) * M, T, pos.as<int>(), 0, 1, T, y.f(), M, s.mimi_heads, s.mimi_ffn,
                 s.mimi_eps, s.mimi_context, model_->mimi_cos, model_->mimi_sin, model_->mimi_tab_len, sc,
                 yd.f() + static_cast<size_t>(U) * M, 0, M, stream_);
     DevBuf d(static_cast<size_t>(Nv) * M * 4), o(static_cast<size_t>(Nv) * D * 4);

@@ -48,7 +48,8 @@ void launch_layernorm(const LayerNormArgs& a, hipStream_t s);
 // position pos[m / rpb] + m % rpb.  cos_tab/sin_tab: [tab_len][dh/2].
 struct RopeAppendArgs {
     const float* qkv = nullptr; float* q_out = nullptr;
-    float* kcache = nullptr; float* vcache = nullptr;  // [slots][cap][d] of one layer
+    void* kcache = nullptr; void* vcache = nullptr;  // [slots][cap][d] of one layer, f32 or (kv16) bf16
+    int kv16 = 0;
     const int* pos = nullptr; int slot0 = 0; int rpb = 1;
     int M = 0, d = 0, heads = 0, cap = 0;
     const float* cos_tab = nullptr; const float* sin_tab = nullptr; int tab_len = 0;
@@ -58,7 +59,8 @@ void launch_rope_append(const RopeAppendArgs& a, hipStream_t s);
 // out[m][h*64..] = softmax(q . K / 8) V over keys max(0, p-window+1)..p of the row's slot (head dim 64).
 struct AttentionArgs {
     const float* q = nullptr; float* out = nullptr;
-    const float* kcache = nullptr; const float* vcache = nullptr;
+    const void* kcache = nullptr; const void* vcache = nullptr;   // f32 or (kv16) bf16
+    int kv16 = 0;
     const int* pos = nullptr; int slot0 = 0; int rpb = 1;
     int M = 0, d = 0, heads = 0, cap = 0, window = 0;  // window <= 0: all earlier keys
 };
@@ -169,8 +171,10 @@ void launch_add_norm(const AddNormArgs& a, hipStream_t s);
 // One new token per row: rotate q/k of qkv[M][3d] at position pos[m], append k/v to slot slot0+m of the
 // cache, attend over the slot's keys (window as in AttentionArgs), write out[M][d].
 struct AttnDecodeArgs {
-    const float* qkv = nullptr;
-    float* kcache = nullptr; float* vcache = nullptr;
+    const float* qkv = nullptr;       // [qkv_splits][M][3d]: K-slice slabs of the QKV product, added in slice order
+    int qkv_splits = 1;
+    void* kcache = nullptr; void* vcache = nullptr;   // f32 or (kv16) bf16
+    int kv16 = 0;
     const int* pos = nullptr; int slot0 = 0;
     int M = 0, d = 0, heads = 0, cap = 0, window = 0;
     const float* cos_tab = nullptr; const float* sin_tab = nullptr; int tab_len = 0;

@@ -64,6 +64,21 @@ void launch_layernorm(const LayerNormArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------ RoPE + KV append
 // One thread per (row, pair): pair index over d/2; q/k pairs rotate, v copies.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+
+// 4 consecutive cache values as float4, from an f32 or a bf16 cache
+template <bool KV16>
+__device__ __forceinline__ float4 kv_load4(const void* base, long long idx) {
+    if constexpr (KV16) {
+        const bf16x4_t v = *(const bf16x4_t*)((const __bf16*)base + idx);
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    } else {
+        return *(const float4*)((const float*)base + idx);
+    }
+}
+
+template <bool KV16>
 __global__ __launch_bounds__(256) void rope_append_kernel(RopeAppendArgs a) {
     const int half = a.d >> 1;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -84,19 +99,28 @@ __global__ __launch_bounds__(256) void rope_append_kernel(RopeAppendArgs a) {
     ko.x = k.x * c - k.y * s; ko.y = k.x * s + k.y * c;
     *(float2*)(a.q_out + (long long)m * a.d + 2 * pi) = qo;
     const long long crow = ((long long)(a.slot0 + b) * a.cap + (p % a.cap)) * a.d + 2 * pi;
-    *(float2*)(a.kcache + crow) = ko;
-    *(float2*)(a.vcache + crow) = v;
+    if constexpr (KV16) {
+        bf16x2_t kb, vb;
+        kb[0] = (__bf16)ko.x; kb[1] = (__bf16)ko.y; vb[0] = (__bf16)v.x; vb[1] = (__bf16)v.y;
+        *(bf16x2_t*)((__bf16*)a.kcache + crow) = kb;
+        *(bf16x2_t*)((__bf16*)a.vcache + crow) = vb;
+    } else {
+        *(float2*)((float*)a.kcache + crow) = ko;
+        *(float2*)((float*)a.vcache + crow) = v;
+    }
 }
 
 void launch_rope_append(const RopeAppendArgs& a, hipStream_t s) {
     if (a.M <= 0) return;
     long long n = (long long)a.M * (a.d / 2);
-    hipLaunchKernelGGL(rope_append_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    if (a.kv16) hipLaunchKernelGGL(rope_append_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(rope_append_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------ cached attention, one wave per (row, head)
 // Pass 1: lane j scores keys j, j+64, ... against q (held by every lane); scores go to LDS.
 // Pass 2: lane e accumulates channel e of the output over all keys (coalesced 256-byte V rows).
+template <bool KV16>
 __global__ __launch_bounds__(256) void attention_kernel(AttentionArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -109,19 +133,18 @@ __global__ __launch_bounds__(256) void attention_kernel(AttentionArgs a) {
     if (a.window > 0 && p - a.window + 1 > 0) j0 = p - a.window + 1;
     const int nk = live ? (p - j0 + 1) : 0;
     float* sc = smem + (long long)w * a.cap;
-    const float* kc = a.kcache + (long long)(a.slot0 + b) * a.cap * a.d + h * 64;
-    const float* vc = a.vcache + (long long)(a.slot0 + b) * a.cap * a.d + h * 64;
+    const long long cbase = (long long)(a.slot0 + b) * a.cap * a.d + h * 64;
     const float* qp = a.q + (long long)m * a.d + h * 64;
     float4 q[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) q[i] = *(const float4*)(qp + 4 * i);
     float mx = -INFINITY;
     for (int j = lane; j < nk; j += 64) {
-        const float* kr = kc + (long long)((j0 + j) % a.cap) * a.d;
+        const long long kr = cbase + (long long)((j0 + j) % a.cap) * a.d;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            float4 kv = *(const float4*)(kr + 4 * i);
+            float4 kv = kv_load4<KV16>(a.kcache, kr + 4 * i);
             s0 += q[i].x * kv.x; s1 += q[i].y * kv.y; s2 += q[i].z * kv.z; s3 += q[i].w * kv.w;
         }
         float sv = ((s0 + s1) + (s2 + s3)) * 0.125f;
@@ -143,10 +166,10 @@ __global__ __launch_bounds__(256) void attention_kernel(AttentionArgs a) {
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     int j = kg;
     for (; j + 12 < nk; j += 16) {
-        const float4 v0 = *(const float4*)(vc + (long long)((j0 + j) % a.cap) * a.d + 4 * cq);
-        const float4 v1 = *(const float4*)(vc + (long long)((j0 + j + 4) % a.cap) * a.d + 4 * cq);
-        const float4 v2 = *(const float4*)(vc + (long long)((j0 + j + 8) % a.cap) * a.d + 4 * cq);
-        const float4 v3 = *(const float4*)(vc + (long long)((j0 + j + 12) % a.cap) * a.d + 4 * cq);
+        const float4 v0 = kv_load4<KV16>(a.vcache, cbase + (long long)((j0 + j) % a.cap) * a.d + 4 * cq);
+        const float4 v1 = kv_load4<KV16>(a.vcache, cbase + (long long)((j0 + j + 4) % a.cap) * a.d + 4 * cq);
+        const float4 v2 = kv_load4<KV16>(a.vcache, cbase + (long long)((j0 + j + 8) % a.cap) * a.d + 4 * cq);
+        const float4 v3 = kv_load4<KV16>(a.vcache, cbase + (long long)((j0 + j + 12) % a.cap) * a.d + 4 * cq);
         const float p0 = sc[j], p1 = sc[j + 4], p2 = sc[j + 8], p3 = sc[j + 12];
         o.x += (p0 * v0.x + p1 * v1.x) + (p2 * v2.x + p3 * v3.x);
         o.y += (p0 * v0.y + p1 * v1.y) + (p2 * v2.y + p3 * v3.y);
@@ -154,7 +177,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttentionArgs a) {
         o.w += (p0 * v0.w + p1 * v1.w) + (p2 * v2.w + p3 * v3.w);
     }
     for (; j < nk; j += 4) {
-        const float4 v0 = *(const float4*)(vc + (long long)((j0 + j) % a.cap) * a.d + 4 * cq);
+        const float4 v0 = kv_load4<KV16>(a.vcache, cbase + (long long)((j0 + j) % a.cap) * a.d + 4 * cq);
         const float p0 = sc[j];
         o.x += p0 * v0.x; o.y += p0 * v0.y; o.z += p0 * v0.z; o.w += p0 * v0.w;
     }
@@ -173,7 +196,8 @@ void launch_attention(const AttentionArgs& a, hipStream_t s) {
     long long items = (long long)a.M * a.heads;
     size_t smem = (size_t)4 * a.cap * sizeof(float);
     if (smem > 160 * 1024) throw std::runtime_error("attention: context capacity too large for LDS score buffer");
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), smem, s, a);
+    if (a.kv16) hipLaunchKernelGGL(attention_kernel<true>, dim3((unsigned)((items + 3) / 4)), dim3(256), smem, s, a);
+    else hipLaunchKernelGGL(attention_kernel<false>, dim3((unsigned)((items + 3) / 4)), dim3(256), smem, s, a);
 }
 
 // ------------------------------------------------------------------ small helpers
