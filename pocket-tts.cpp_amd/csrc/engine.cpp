@@ -420,29 +420,35 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
         throw std::runtime_error("no HIP device available: the MI355X engine has no CPU fallback");
     if (opt_.device < 0 || opt_.device >= ndev) throw std::runtime_error("engine: device ordinal out of range");
     PTTS_HIP(hipSetDevice(opt_.device));
-    // Optional spatial split of the compute units between the latency-bound frame loop and the decoder's wide
-    // kernels (POCKET_TTS_FRAME_CU_EIGHTHS = k in 1..7: the frame-loop stream gets k of every 8 blocks of 8 CUs,
-    // the decoder stream the rest), so that a decoder launch cannot queue in front of a 16-workgroup flow block.
-    int eighths = 0;
-    if (const char* e = std::getenv("POCKET_TTS_FRAME_CU_EIGHTHS")) eighths = std::atoi(e);
-    if (eighths >= 1 && eighths <= 7) {
+    // Spatial split of the compute units: the decoder stream is confined to k of every 8 blocks of 8 CUs
+    // (POCKET_TTS_DECODER_CU_EIGHTHS, default 4, 0 = no mask), so its wide kernels always leave CUs free for the
+    // frame loop's small dependent launches.  Measured at B = 64 on MI355X: no mask 3350 RTFx, k = 4 3620, k = 3 3540,
+    // k = 2 3350, k >= 5 no gain.  POCKET_TTS_FRAME_CU_EIGHTHS = k additionally confines the frame loop to the
+    // other blocks instead of letting it use the whole chip (slower: the decode attention wants every CU).
+    int dec_eighths = 4, frame_eighths = 0;
+    if (const char* e = std::getenv("POCKET_TTS_DECODER_CU_EIGHTHS")) dec_eighths = std::atoi(e);
+    if (const char* e = std::getenv("POCKET_TTS_FRAME_CU_EIGHTHS")) { frame_eighths = std::atoi(e); dec_eighths = 8 - frame_eighths; }
+    int lo = 0, hi = 0;
+    PTTS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (dec_eighths >= 1 && dec_eighths <= 7) {
         hipDeviceProp_t prop;
         PTTS_HIP(hipGetDeviceProperties(&prop, opt_.device));
         const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
         std::vector<uint32_t> main_mask(words, 0u), dec_mask(words, 0u);
         for (int i = 0; i < ncu; ++i) {
-            const bool to_main = (i / 8) % 8 < eighths;
-            (to_main ? main_mask : dec_mask)[i / 32] |= 1u << (i % 32);
+            const bool to_dec = (i / 8) % 8 >= 8 - dec_eighths;
+            (to_dec ? dec_mask : main_mask)[i / 32] |= 1u << (i % 32);
         }
-        PTTS_HIP(hipExtStreamCreateWithCUMask(&stream_, words, main_mask.data()));
-        PTTS_HIP(hipExtStreamCreateWithCUMask(&dec_stream_, words, dec_mask.data()));
+        if (frame_eighths >= 1) PTTS_HIP(hipExtStreamCreateWithCUMask(&stream_, words, main_mask.data()));
+        else PTTS_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
+        if (hipExtStreamCreateWithCUMask(&dec_stream_, words, dec_mask.data()) != hipSuccess) {
+            (void)hipGetLastError();   // masks unsupported here: an ordinary low-priority stream does the job, only slower
+            PTTS_HIP(hipStreamCreateWithPriority(&dec_stream_, hipStreamNonBlocking, lo));
+        }
     } else {
         // the frame loop's small dependent launches go ahead of the decoder's wide ones whenever both are ready
-        int lo = 0, hi = 0;
-        PTTS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const bool prio = std::getenv("POCKET_TTS_NO_STREAM_PRIORITY") == nullptr;
-        PTTS_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, prio ? hi : 0));
-        PTTS_HIP(hipStreamCreateWithPriority(&dec_stream_, hipStreamNonBlocking, prio ? lo : 0));
+        PTTS_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
+        PTTS_HIP(hipStreamCreateWithPriority(&dec_stream_, hipStreamNonBlocking, lo));
     }
     PTTS_HIP(hipEventCreateWithFlags(&latents_ready_, hipEventDisableTiming));
     PTTS_HIP(hipEventCreateWithFlags(&dec_done_, hipEventDisableTiming));
