@@ -308,7 +308,17 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
             if (stop) {
                 int fmax = 0;
                 for (int i = 0; i < B; ++i) fmax = std::max(fmax, frames_out[r.first + i]);
-                for (int f0 = r.decoded; f0 < fmax; f0 += kDecChunk) decode_chunk(r, f0, std::min(kDecChunk, fmax - f0));  // :454-546
+                // The frames left over (:454-546) are decoded on the frame-loop stream, which has the whole chip now
+                // that the loop has ended, behind whatever the (CU-masked) decoder stream still has queued.
+                if (b.dec_st != b.st && r.decoded < fmax) {
+                    PTTS_HIP(hipEventRecord(dec_done_, b.dec_st));
+                    PTTS_HIP(hipStreamWaitEvent(b.st, dec_done_, 0));
+                }
+                for (int f0 = r.decoded; f0 < fmax; f0 += kDecChunk) {
+                    const int n = std::min(kDecChunk, fmax - f0);
+                    mimi_decode_dev(b, b.latents.f() + static_cast<size_t>(f0) * L, static_cast<long long>(opt_.max_frames) * L, n,
+                                    b.audio_all.f() + static_cast<size_t>(f0) * fs, static_cast<long long>(opt_.max_frames) * fs, b.st);
+                }
                 r.finished = true;
                 ++n_finished;
             }
