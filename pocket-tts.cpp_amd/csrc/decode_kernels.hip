@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <algorithm>
 #include <stdexcept>
 #include <type_traits>
 #include <vector>
@@ -391,37 +392,54 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     const int p = a.pos[m];
     const int pc = p < a.tab_len ? p : a.tab_len - 1;
     const float cs = a.cos_tab[(long long)pc * 32 + (lane >> 1)], sn = a.sin_tab[(long long)pc * 32 + (lane >> 1)];
+    const long long cbase = (long long)(a.slot0 + m) * a.cap * a.d + h * 64;
+    int j0 = 0;
+    if (a.window > 0 && p - a.window + 1 > 0) j0 = p - a.window + 1;
+    const int nk = p - j0;                    // earlier keys only
+    const int chunk = ((nk + 3) / 4 + 3) & ~3; // keys per wave, multiple of 4
+    const int kb = w * chunk, ke = min(nk, kb + chunk), cnt = max(ke - kb, 0);
+    const int kg = lane >> 4, cq = lane & 15;
     const float* row = a.qkv + (long long)m * 3 * a.d + h * 64;
     float qv = row[lane], kv = row[a.d + lane], vv = row[2 * a.d + lane];
     for (int s = 1; s < a.qkv_splits; ++s) {
         const float* rs = row + (long long)s * a.M * 3 * a.d;
         qv += rs[lane]; kv += rs[a.d + lane]; vv += rs[2 * a.d + lane];
     }
+    // bf16 cache, at most 64 keys for this wave: every K and V element the wave needs is requested here, before
+    // anything waits on q, so the step pays one cache round trip instead of three dependent ones.  Out-of-range
+    // keys re-read the wave's last key (their weight is zero below).
+    bf16x8 kreg[8];
+    bf16x4 vreg[16];
+    const bool early = KV16 && cnt > 0 && cnt <= 64;
+    if constexpr (KV16) {
+        if (early) {
+            const int jk = lane < cnt ? lane : cnt - 1;
+            const __bf16* kp = (const __bf16*)a.kcache + cbase + (long long)((j0 + kb + jk) % a.cap) * a.d;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kreg[i] = *(const bf16x8*)(kp + 8 * i);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int jv = kg + 4 * i < cnt ? kg + 4 * i : cnt - 1;
+                vreg[i] = *(const bf16x4*)((const __bf16*)a.vcache + cbase + (long long)((j0 + kb + jv) % a.cap) * a.d + 4 * cq);
+            }
+        }
+    }
     const float qo = __shfl_xor(qv, 1, 64), ko = __shfl_xor(kv, 1, 64);
     // pair (2i, 2i+1): even lane x*c - y*s, odd lane x*s + y*c, with x the even and y the odd element
     const float qr = (lane & 1) ? (qo * sn + qv * cs) : (qv * cs - qo * sn);
     const float kr = (lane & 1) ? (ko * sn + kv * cs) : (kv * cs - ko * sn);
-    const long long cbase = (long long)(a.slot0 + m) * a.cap * a.d + h * 64;
     if (w == 0) {
         const long long at = cbase + (long long)(p % a.cap) * a.d + lane;
         if constexpr (KV16) { ((__bf16*)a.kcache)[at] = (__bf16)kr; ((__bf16*)a.vcache)[at] = (__bf16)vv; }
         else { ((float*)a.kcache)[at] = kr; ((float*)a.vcache)[at] = vv; }
     }
-    int j0 = 0;
-    if (a.window > 0 && p - a.window + 1 > 0) j0 = p - a.window + 1;
-    const int nk = p - j0;                    // earlier keys only
-    const int chunk = ((nk + 3) / 4 + 3) & ~3; // keys per wave, multiple of 4
-    const int kb = w * chunk, ke = min(nk, kb + chunk), cnt = max(ke - kb, 0);
-    const int scap = (a.cap / 4 + 8) & ~3;
+    const int scap = max((a.cap / 4 + 8) & ~3, 64);
     float* qs = smem + (long long)w * (64 + scap);
     float* sc = qs + 64;
     float* comb = smem + 4ll * (64 + scap);   // [4][68]: max, sum, pad, pad, out[64]
     qs[lane] = qr;
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    float4 q[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) q[i] = *(const float4*)(qs + 4 * i);
     auto ld4 = [&](const void* base, long long idx) -> float4 {
         if constexpr (KV16) {
             const bf16x4 v = *(const bf16x4*)((const __bf16*)base + idx);
@@ -430,57 +448,90 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
             return *(const float4*)((const float*)base + idx);
         }
     };
-    float mx = -INFINITY;
-    for (int j = lane; j < cnt; j += 64) {
-        const long long kr_ = cbase + (long long)((j0 + kb + j) % a.cap) * a.d;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        if constexpr (KV16) {
+    float mx = -INFINITY, sum = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool done = false;
+    if constexpr (KV16) {
+        if (early) {
+            // scores: lane = key, q broadcast from LDS
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const bf16x8 k8 = *(const bf16x8*)((const __bf16*)a.kcache + kr_ + 8 * i);
-                s0 += q[2 * i].x * (float)k8[0]; s1 += q[2 * i].y * (float)k8[1]; s2 += q[2 * i].z * (float)k8[2]; s3 += q[2 * i].w * (float)k8[3];
-                s0 += q[2 * i + 1].x * (float)k8[4]; s1 += q[2 * i + 1].y * (float)k8[5]; s2 += q[2 * i + 1].z * (float)k8[6]; s3 += q[2 * i + 1].w * (float)k8[7];
+                const float4 qa = *(const float4*)(qs + 8 * i), qb = *(const float4*)(qs + 8 * i + 4);
+                const bf16x8 k8 = kreg[i];
+                s0 += qa.x * (float)k8[0]; s1 += qa.y * (float)k8[1]; s2 += qa.z * (float)k8[2]; s3 += qa.w * (float)k8[3];
+                s0 += qb.x * (float)k8[4]; s1 += qb.y * (float)k8[5]; s2 += qb.z * (float)k8[6]; s3 += qb.w * (float)k8[7];
             }
-        } else {
+            const float sv = lane < cnt ? ((s0 + s1) + (s2 + s3)) * 0.125f : -INFINITY;
+            mx = sv;
+#pragma unroll
+            for (int of = 32; of > 0; of >>= 1) mx = fmaxf(mx, __shfl_xor(mx, of, 64));
+            const float e = lane < cnt ? expf(sv - mx) : 0.f;
+            sc[lane] = e;
+            sum = wsum64(e);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float4 k4 = *(const float4*)((const float*)a.kcache + kr_ + 4 * i);
-                s0 += q[i].x * k4.x; s1 += q[i].y * k4.y; s2 += q[i].z * k4.z; s3 += q[i].w * k4.w;
+                const float pw = sc[kg + 4 * i];      // zero for keys past cnt
+                const bf16x4 v = vreg[i];
+                o.x += pw * (float)v[0]; o.y += pw * (float)v[1]; o.z += pw * (float)v[2]; o.w += pw * (float)v[3];
             }
+            done = true;
         }
-        const float sv = ((s0 + s1) + (s2 + s3)) * 0.125f;
-        sc[j] = sv;
-        mx = fmaxf(mx, sv);
     }
+    if (!done) {
+        float4 q[16];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    float sum = 0.f;
-    for (int j = lane; j < cnt; j += 64) {
-        const float e = expf(sc[j] - mx);
-        sc[j] = e;
-        sum += e;
-    }
-    sum = wsum64(sum);
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    const int kg = lane >> 4, cq = lane & 15;
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    int j = kg;
-    for (; j + 12 < cnt; j += 16) {
-        const float4 v0 = ld4(a.vcache, cbase + (long long)((j0 + kb + j) % a.cap) * a.d + 4 * cq);
-        const float4 v1 = ld4(a.vcache, cbase + (long long)((j0 + kb + j + 4) % a.cap) * a.d + 4 * cq);
-        const float4 v2 = ld4(a.vcache, cbase + (long long)((j0 + kb + j + 8) % a.cap) * a.d + 4 * cq);
-        const float4 v3 = ld4(a.vcache, cbase + (long long)((j0 + kb + j + 12) % a.cap) * a.d + 4 * cq);
-        const float p0 = sc[j], p1 = sc[j + 4], p2 = sc[j + 8], p3 = sc[j + 12];
-        o.x += (p0 * v0.x + p1 * v1.x) + (p2 * v2.x + p3 * v3.x);
-        o.y += (p0 * v0.y + p1 * v1.y) + (p2 * v2.y + p3 * v3.y);
-        o.z += (p0 * v0.z + p1 * v1.z) + (p2 * v2.z + p3 * v3.z);
-        o.w += (p0 * v0.w + p1 * v1.w) + (p2 * v2.w + p3 * v3.w);
-    }
-    for (; j < cnt; j += 4) {
-        const float4 v0 = ld4(a.vcache, cbase + (long long)((j0 + kb + j) % a.cap) * a.d + 4 * cq);
-        const float p0 = sc[j];
-        o.x += p0 * v0.x; o.y += p0 * v0.y; o.z += p0 * v0.z; o.w += p0 * v0.w;
+        for (int i = 0; i < 16; ++i) q[i] = *(const float4*)(qs + 4 * i);
+        for (int j = lane; j < cnt; j += 64) {
+            const long long kr_ = cbase + (long long)((j0 + kb + j) % a.cap) * a.d;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            if constexpr (KV16) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bf16x8 k8 = *(const bf16x8*)((const __bf16*)a.kcache + kr_ + 8 * i);
+                    s0 += q[2 * i].x * (float)k8[0]; s1 += q[2 * i].y * (float)k8[1]; s2 += q[2 * i].z * (float)k8[2]; s3 += q[2 * i].w * (float)k8[3];
+                    s0 += q[2 * i + 1].x * (float)k8[4]; s1 += q[2 * i + 1].y * (float)k8[5]; s2 += q[2 * i + 1].z * (float)k8[6]; s3 += q[2 * i + 1].w * (float)k8[7];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float4 k4 = *(const float4*)((const float*)a.kcache + kr_ + 4 * i);
+                    s0 += q[i].x * k4.x; s1 += q[i].y * k4.y; s2 += q[i].z * k4.z; s3 += q[i].w * k4.w;
+                }
+            }
+            const float sv = ((s0 + s1) + (s2 + s3)) * 0.125f;
+            sc[j] = sv;
+            mx = fmaxf(mx, sv);
+        }
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) mx = fmaxf(mx, __shfl_xor(mx, of, 64));
+        for (int j = lane; j < cnt; j += 64) {
+            const float e = expf(sc[j] - mx);
+            sc[j] = e;
+            sum += e;
+        }
+        sum = wsum64(sum);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        int j = kg;
+        for (; j + 12 < cnt; j += 16) {
+            const float4 v0 = ld4(a.vcache, cbase + (long long)((j0 + kb + j) % a.cap) * a.d + 4 * cq);
+            const float4 v1 = ld4(a.vcache, cbase + (long long)((j0 + kb + j + 4) % a.cap) * a.d + 4 * cq);
+            const float4 v2 = ld4(a.vcache, cbase + (long long)((j0 + kb + j + 8) % a.cap) * a.d + 4 * cq);
+            const float4 v3 = ld4(a.vcache, cbase + (long long)((j0 + kb + j + 12) % a.cap) * a.d + 4 * cq);
+            const float p0 = sc[j], p1 = sc[j + 4], p2 = sc[j + 8], p3 = sc[j + 12];
+            o.x += (p0 * v0.x + p1 * v1.x) + (p2 * v2.x + p3 * v3.x);
+            o.y += (p0 * v0.y + p1 * v1.y) + (p2 * v2.y + p3 * v3.y);
+            o.z += (p0 * v0.z + p1 * v1.z) + (p2 * v2.z + p3 * v3.z);
+            o.w += (p0 * v0.w + p1 * v1.w) + (p2 * v2.w + p3 * v3.w);
+        }
+        for (; j < cnt; j += 4) {
+            const float4 v0 = ld4(a.vcache, cbase + (long long)((j0 + kb + j) % a.cap) * a.d + 4 * cq);
+            const float p0 = sc[j];
+            o.x += p0 * v0.x; o.y += p0 * v0.y; o.z += p0 * v0.z; o.w += p0 * v0.w;
+        }
     }
     o.x += __shfl_xor(o.x, 16, 64); o.y += __shfl_xor(o.y, 16, 64); o.z += __shfl_xor(o.z, 16, 64); o.w += __shfl_xor(o.w, 16, 64);
     o.x += __shfl_xor(o.x, 32, 64); o.y += __shfl_xor(o.y, 32, 64); o.z += __shfl_xor(o.z, 32, 64); o.w += __shfl_xor(o.w, 32, 64);
@@ -509,7 +560,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     if (a.M <= 0) return;
     if (a.d != a.heads * 64) throw std::runtime_error("attention: head dimension must be 64");
-    const int scap = (a.cap / 4 + 8) & ~3;
+    const int scap = std::max((a.cap / 4 + 8) & ~3, 64);
     const size_t smem = ((size_t)4 * (64 + scap) + 4 * 68) * sizeof(float);
     if (smem > 64 * 1024) throw std::runtime_error("attention: context capacity too large for the LDS score buffer");
     dim3 grid((unsigned)(a.M * a.heads)), block(256);

@@ -135,6 +135,20 @@ static void bench_flow(int B) {
     std::printf("   = %.2f us per launch over %d launches\n", us / (steps * (nb + 1)), steps * (nb + 1));
 }
 
+static void bench_attn_decode(int ctx, int kv16) {
+    const int M = 64, d = 1024, heads = 16, cap = 256, splits = 4;
+    AttnDecodeArgs a;
+    a.qkv = (const float*)dalloc((size_t)splits * M * 3 * d * 4); a.qkv_splits = splits;
+    a.kcache = dalloc((size_t)M * cap * d * 4); a.vcache = dalloc((size_t)M * cap * d * 4); a.kv16 = kv16;
+    std::vector<int> pos(M, ctx);
+    int* dp = nullptr; CK(hipMalloc(&dp, M * 4)); CK(hipMemcpy(dp, pos.data(), M * 4, hipMemcpyHostToDevice));
+    a.pos = dp; a.M = M; a.d = d; a.heads = heads; a.cap = cap;
+    a.cos_tab = (const float*)dalloc(1024 * 32 * 4); a.sin_tab = (const float*)dalloc(1024 * 32 * 4); a.tab_len = 1024;
+    a.out = (float*)dalloc((size_t)M * d * 4, 0);
+    time_it(kv16 ? "attn_decode_bf16" : "attn_decode_f32", 300, [&](hipStream_t s) { launch_attn_decode(a, s); },
+            2.0 * M * ctx * d * (kv16 ? 2 : 4) + (double)splits * M * 3 * d * 4, 4.0 * M * ctx * d);
+}
+
 int main(int argc, char** argv) {
     std::vector<std::string> cases;
     for (int i = 1; i < argc; ++i) cases.push_back(argv[i]);
@@ -158,6 +172,7 @@ int main(int argc, char** argv) {
     if (want("gemm_dec_up2")) bench_gemm("gemm_dec_up2", 460800, 256, 256, 0, 128);
     if (want("gemm_dec_c1_2")) bench_gemm("gemm_dec_c1_2", 1843200, 32, 192, 0, 64);
     if (want("gemm_dec_c2_2")) bench_gemm("gemm_dec_c2_2", 1843200, 64, 32, 0, 32);
+    if (want("attn_decode")) { bench_attn_decode(156, 1); bench_attn_decode(156, 0); }
     if (want("flow")) bench_flow(64);
     return 0;
 }
