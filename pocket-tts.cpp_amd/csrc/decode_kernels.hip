@@ -52,21 +52,22 @@ __device__ __forceinline__ float act_dev(float v, int act) {
     }
 }
 
-template <typename CT>
+template <typename CT, int MT, int KCH>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     using T = SkinnyTraits<CT>;
+    constexpr int ROWS = 16 * MT;           // rows per workgroup
     constexpr bool kBf16 = !std::is_same<CT, float>::value;
-    constexpr int KSTEP = T::kstep, KCH = T::kch, LDA = KCH + T::pad;
+    constexpr int KSTEP = T::kstep, LDA = KCH + T::pad;
     constexpr int NKS = KCH / KSTEP;        // k-steps per chunk
     constexpr int PIECES = KCH / 4;         // float4 pieces per row of a chunk (32)
-    constexpr int APT = 64 * PIECES / 256;  // A pieces per thread per chunk (8)
+    constexpr int APT = ROWS * PIECES / 256;  // A pieces per thread per chunk (8 at 64 rows)
     constexpr int PLANES = kBf16 ? 2 : 1;   // bf16: hi and lo planes
-    __shared__ __attribute__((aligned(16))) CT As[2][PLANES][64 * LDA];
+    __shared__ __attribute__((aligned(16))) CT As[2][PLANES][ROWS * LDA];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x * 4 + wave;
     const bool tile_live = nt * 16 < a.N;
-    const int m0 = blockIdx.z * 64;
+    const int m0 = blockIdx.z * ROWS;
     const int Kc = a.K / a.splits;
     const int k_begin = blockIdx.y * Kc;
     const int nchunks = (Kc + KCH - 1) / KCH;
@@ -91,9 +92,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
         }
     };
 
-    f32x4 acc[4];
+    f32x4 acc[MT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r = lane & 15, g = lane >> 4;
 
     load_chunk(0);
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
         for (int ks = 0; ks < NKS; ++ks) {
             if constexpr (!kBf16) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     const float4 a4 = *(const float4*)(buf + (mt * 16 + r) * LDA + ks * 16 + 4 * g);
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, __uint_as_float(bcur[ks].x), acc[mt], 0, 0, 0);
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, __uint_as_float(bcur[ks].y), acc[mt], 0, 0, 0);
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
             } else {
                 const bf16x8 b8 = __builtin_bit_cast(bf16x8, bcur[ks]);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     const bf16x8 lo8 = *(const bf16x8*)(buf_lo + (mt * 16 + r) * LDA + ks * 32 + 8 * g);
                     const bf16x8 hi8 = *(const bf16x8*)(buf + (mt * 16 + r) * LDA + ks * 32 + 8 * g);
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo8, b8, acc[mt], 0, 0, 0);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     if (!tile_live) return;
     const int col = nt * 16 + r;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = m0 + mt * 16 + g * 4 + i;
@@ -304,9 +305,37 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
         throw std::runtime_error("skinny gemm: shape not tileable (N % 16, K % k-step, K % splits, lda alignment)");
     if (!a.P && a.splits != 1) throw std::runtime_error("skinny gemm: split K needs a partial buffer");
     dim3 grid((a.N + 63) / 64, a.splits, (a.M + 63) / 64), block(256);
-    if (a.wtype == W_I8) hipLaunchKernelGGL(skinny_q8_kernel, grid, block, 0, s, a);
-    else if (bf) hipLaunchKernelGGL(skinny_gemm_kernel<__bf16>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(skinny_gemm_kernel<float>, grid, block, 0, s, a);
+    if (a.wtype == W_I8) { hipLaunchKernelGGL(skinny_q8_kernel, grid, block, 0, s, a); return; }
+    // rows per workgroup: 64, 32 or 16.  Fewer rows = more workgroups streaming the same weights (served by the
+    // XCD's L2 after the first: same-column workgroups differ by a multiple of 8 in linear id when grid.x * grid.y
+    // is one) and a shorter LDS / MFMA phase per K chunk.
+    // Measured at M = 64 (QKV / FFN / output products of the LM step): the time of a launch follows the LDS + MFMA
+    // work per workgroup, not the bytes, until there are about 200 workgroups; 16-row workgroups are 2x faster
+    // than 64-row ones on the unsplit products.
+    int mt = a.mtiles;
+    if (mt != 1 && mt != 2 && mt != 4) {
+        const long long cols = (long long)grid.x * grid.y;
+        mt = 4;
+        while (mt > 1 && cols * ((a.M + 16 * mt - 1) / (16 * mt)) < 192) mt >>= 1;
+        if (a.M <= 16 * (mt / 2)) mt = a.M <= 16 ? 1 : 2;     // never stage rows that do not exist
+    }
+    grid.z = (a.M + 16 * mt - 1) / (16 * mt);
+    const int Kc = a.K / a.splits;
+    int kch = a.kchunk;
+    if (kch != 128 && kch != 256 && kch != 512) kch = (mt == 1 && Kc >= 1024) ? 512 : (mt <= 2 && Kc >= 256) ? 256 : 128;
+    if (Kc % kch) kch = 128;
+    if (bf) {
+        if (mt == 1 && kch == 512) hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 1, 512>), grid, block, 0, s, a);
+        else if (mt == 1 && kch == 256) hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 1, 256>), grid, block, 0, s, a);
+        else if (mt == 1) hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 1, 128>), grid, block, 0, s, a);
+        else if (mt == 2 && kch == 256) hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 2, 256>), grid, block, 0, s, a);
+        else if (mt == 2) hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 2, 128>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 4, 128>), grid, block, 0, s, a);
+    } else {
+        if (mt == 1) hipLaunchKernelGGL((skinny_gemm_kernel<float, 1, 128>), grid, block, 0, s, a);
+        else if (mt == 2) hipLaunchKernelGGL((skinny_gemm_kernel<float, 2, 128>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<float, 4, 128>), grid, block, 0, s, a);
+    }
 }
 
 // ------------------------------------------------------------------ add & norm, one 256-thread block per row

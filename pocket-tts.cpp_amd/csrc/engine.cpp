@@ -749,11 +749,11 @@ void Engine::lm_rows_q8(Batch& b, int slot0, int nb, int rpb, float* X) {
     }
 }
 
-// K-slices for a split-K product: about 256 deep each, at most 16, dividing K into k-step multiples.
+// K-slices for a split-K product: about 256 deep each, at most 8, dividing K into k-step multiples.
 static int pick_splits(int K, int kstep) {
     int s = K / 256;
     if (s < 1) s = 1;
-    if (s > 16) s = 16;
+    if (s > 8) s = 8;
     while (s > 1 && (K % s != 0 || (K / s) % kstep != 0)) --s;
     return s;
 }

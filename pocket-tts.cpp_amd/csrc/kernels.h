@@ -150,6 +150,8 @@ struct SkinnyArgs {
     float* C = nullptr; int ldc = 0;
     float* P = nullptr;
     const float* wscale = nullptr;   // W_I8: per-output-column weight scale
+    int mtiles = 0;                  // 16-row tiles per workgroup: 1, 2 or 4 (0 = 4)
+    int kchunk = 0;                  // K elements staged per step: 128, 256 or 512 (bf16, mtiles <= 2); 0 = 128
 };
 void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s);
 

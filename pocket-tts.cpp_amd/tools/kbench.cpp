@@ -76,8 +76,9 @@ static void* bf16_weight(int N, int K) {
     return p;
 }
 
-static void bench_skinny(const char* name, int M, int N, int K, int splits) {
+static void bench_skinny(const char* name, int M, int N, int K, int splits, int mt = 0, int kch = 0) {
     SkinnyArgs a;
+    a.mtiles = mt; a.kchunk = kch;
     a.A = (const float*)dalloc((size_t)M * K * 4); a.lda = K;
     a.Wp = packed_weight(N, K, W_BF16); a.wtype = W_BF16;
     a.M = M; a.N = N; a.K = K; a.splits = splits;
@@ -172,6 +173,34 @@ int main(int argc, char** argv) {
     if (want("gemm_dec_up2")) bench_gemm("gemm_dec_up2", 460800, 256, 256, 0, 128);
     if (want("gemm_dec_c1_2")) bench_gemm("gemm_dec_c1_2", 1843200, 32, 192, 0, 64);
     if (want("gemm_dec_c2_2")) bench_gemm("gemm_dec_c2_2", 1843200, 64, 32, 0, 32);
+    if (want("skinny_sweep")) {
+        for (int mt : {4, 2, 1})
+            for (int sp : {1, 2, 4}) {
+                char nm[64];
+                std::snprintf(nm, sizeof nm, "qkv mt%d sp%d", mt, sp); bench_skinny(nm, 64, 3072, 1024, sp, mt);
+                std::snprintf(nm, sizeof nm, "ff1 mt%d sp%d", mt, sp); bench_skinny(nm, 64, 4096, 1024, sp, mt);
+            }
+        for (int mt : {4, 2, 1})
+            for (int sp : {2, 4, 8, 16}) {
+                char nm[64];
+                std::snprintf(nm, sizeof nm, "out mt%d sp%d", mt, sp); bench_skinny(nm, 64, 1024, 1024, sp, mt);
+                std::snprintf(nm, sizeof nm, "ff2 mt%d sp%d", mt, sp); bench_skinny(nm, 64, 1024, 4096, sp, mt);
+            }
+    }
+    if (want("skinny_kch")) {
+        for (int mt : {2, 1})
+            for (int kch : {128, 256, 512}) {
+                if (mt == 2 && kch == 512) continue;
+                char nm[64];
+                std::snprintf(nm, sizeof nm, "qkv mt%d k%d sp1", mt, kch); bench_skinny(nm, 64, 3072, 1024, 1, mt, kch);
+                std::snprintf(nm, sizeof nm, "qkv mt%d k%d sp2", mt, kch); bench_skinny(nm, 64, 3072, 1024, 2, mt, kch);
+                std::snprintf(nm, sizeof nm, "ff1 mt%d k%d sp1", mt, kch); bench_skinny(nm, 64, 4096, 1024, 1, mt, kch);
+                std::snprintf(nm, sizeof nm, "out mt%d k%d sp4", mt, kch); bench_skinny(nm, 64, 1024, 1024, 4, mt, kch);
+                std::snprintf(nm, sizeof nm, "out mt%d k%d sp8", mt, kch); bench_skinny(nm, 64, 1024, 1024, 8, mt, kch);
+                std::snprintf(nm, sizeof nm, "ff2 mt%d k%d sp8", mt, kch); bench_skinny(nm, 64, 1024, 4096, 8, mt, kch);
+                std::snprintf(nm, sizeof nm, "ff2 mt%d k%d sp16", mt, kch); bench_skinny(nm, 64, 1024, 4096, 16, mt, kch);
+            }
+    }
     if (want("attn_decode")) { bench_attn_decode(156, 1); bench_attn_decode(156, 0); }
     if (want("flow")) bench_flow(64);
     return 0;
