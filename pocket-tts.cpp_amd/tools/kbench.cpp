@@ -187,6 +187,17 @@ int main(int argc, char** argv) {
                 std::snprintf(nm, sizeof nm, "ff2 mt%d sp%d", mt, sp); bench_skinny(nm, 64, 1024, 4096, sp, mt);
             }
     }
+    if (want("skinny_ada")) {
+        for (int mt : {4, 2, 1})
+            for (int kch : {128, 256}) {
+                char nm[64];
+                std::snprintf(nm, sizeof nm, "ada mt%d k%d", mt, kch); bench_skinny(nm, 640, 10240, 512, 1, mt, kch);
+            }
+        bench_skinny("cond sp4 auto", 64, 512, 1024, 4);
+        bench_skinny("cond sp8 auto", 64, 512, 1024, 8);
+        bench_skinny("cond sp1 mt1", 64, 512, 1024, 1, 1, 512);
+        bench_skinny("cond sp2 mt1", 64, 512, 1024, 2, 1, 512);
+    }
     if (want("skinny_kch")) {
         for (int mt : {2, 1})
             for (int kch : {128, 256, 512}) {
