@@ -182,15 +182,17 @@ __device__ __forceinline__ float block_absmax16(const float4 v) {
     return m;
 }
 
+template <int MT>
 __global__ __launch_bounds__(256) void skinny_q8_kernel(SkinnyArgs a) {
-    constexpr int KSTEP = 64, KCH = 128, LDA = KCH + 16, NKS = KCH / KSTEP, PIECES = KCH / 4, APT = 64 * PIECES / 256;
-    __shared__ __attribute__((aligned(16))) signed char As[2][64 * LDA];
-    __shared__ __attribute__((aligned(16))) float Dq[2][NKS][64];
+    constexpr int ROWS = 16 * MT;
+    constexpr int KSTEP = 64, KCH = 128, LDA = KCH + 16, NKS = KCH / KSTEP, PIECES = KCH / 4, APT = ROWS * PIECES / 256;
+    __shared__ __attribute__((aligned(16))) signed char As[2][ROWS * LDA];
+    __shared__ __attribute__((aligned(16))) float Dq[2][NKS][ROWS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nt = blockIdx.x * 4 + wave;
     const bool tile_live = nt * 16 < a.N;
-    const int m0 = blockIdx.z * 64;
+    const int m0 = blockIdx.z * ROWS;
     const int Kc = a.K / a.splits;
     const int k_begin = blockIdx.y * Kc;
     const int nchunks = (Kc + KCH - 1) / KCH;
@@ -215,9 +217,9 @@ __global__ __launch_bounds__(256) void skinny_q8_kernel(SkinnyArgs a) {
         }
     };
 
-    f32x4 acc[4];
+    f32x4 acc[MT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r = lane & 15, g = lane >> 4;
 
     load_chunk(0);
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void skinny_q8_kernel(SkinnyArgs a) {
         for (int ks = 0; ks < NKS; ++ks) {
             const i32x4 b4 = __builtin_bit_cast(i32x4, bcur[ks]);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 const i32x4 a4 = *(const i32x4*)(buf + (mt * 16 + r) * LDA + ks * 64 + 16 * g);
                 const i32x4 z = {0, 0, 0, 0};
                 const i32x4 ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a4, b4, z, 0, 0, 0);
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void skinny_q8_kernel(SkinnyArgs a) {
     const int col = nt * 16 + r;
     const float ws = a.wscale[col];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = m0 + mt * 16 + g * 4 + i;
@@ -305,7 +307,6 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
         throw std::runtime_error("skinny gemm: shape not tileable (N % 16, K % k-step, K % splits, lda alignment)");
     if (!a.P && a.splits != 1) throw std::runtime_error("skinny gemm: split K needs a partial buffer");
     dim3 grid((a.N + 63) / 64, a.splits, (a.M + 63) / 64), block(256);
-    if (a.wtype == W_I8) { hipLaunchKernelGGL(skinny_q8_kernel, grid, block, 0, s, a); return; }
     // rows per workgroup: 64, 32 or 16.  Fewer rows = more workgroups streaming the same weights (served by the
     // XCD's L2 after the first: same-column workgroups differ by a multiple of 8 in linear id when grid.x * grid.y
     // is one) and a shorter LDS / MFMA phase per K chunk.
@@ -320,6 +321,12 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
         if (a.M <= 16 * (mt / 2)) mt = a.M <= 16 ? 1 : 2;     // never stage rows that do not exist
     }
     grid.z = (a.M + 16 * mt - 1) / (16 * mt);
+    if (a.wtype == W_I8) {
+        if (mt == 1) hipLaunchKernelGGL(skinny_q8_kernel<1>, grid, block, 0, s, a);
+        else if (mt == 2) hipLaunchKernelGGL(skinny_q8_kernel<2>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(skinny_q8_kernel<4>, grid, block, 0, s, a);
+        return;
+    }
     const int Kc = a.K / a.splits;
     int kch = a.kchunk;
     if (kch != 128 && kch != 256 && kch != 512) kch = (mt == 1 && Kc >= 1024) ? 512 : (mt <= 2 && Kc >= 256) ? 256 : 128;

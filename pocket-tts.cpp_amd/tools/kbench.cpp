@@ -87,7 +87,7 @@ static void bench_skinny(const char* name, int M, int N, int K, int splits, int 
     time_it(name, 300, [&](hipStream_t s) { launch_skinny_gemm(a, s); }, (double)N * K * 2 + (double)M * K * 4 + (double)M * N * 4 * splits, 2.0 * M * N * K);
 }
 
-static void bench_skinny_q8(const char* name, int M, int N, int K, int splits) {
+static void bench_skinny_q8(const char* name, int M, int N, int K, int splits, int mt = 0) {
     auto w = rnd((size_t)N * K);
     std::vector<float> sc;
     auto bytes = pack_q8_weight(w.data(), N, K, sc);
@@ -97,7 +97,7 @@ static void bench_skinny_q8(const char* name, int M, int N, int K, int splits) {
     float* sp = (float*)dalloc(sc.size() * 4);
     SkinnyArgs a;
     a.A = (const float*)dalloc((size_t)M * K * 4); a.lda = K;
-    a.Wp = wp; a.wtype = W_I8; a.wscale = sp;
+    a.Wp = wp; a.wtype = W_I8; a.wscale = sp; a.mtiles = mt;
     a.M = M; a.N = N; a.K = K; a.splits = splits;
     if (splits > 1) a.P = (float*)dalloc((size_t)splits * M * N * 4, 0);
     else { a.C = (float*)dalloc((size_t)M * N * 4, 0); a.ldc = N; }
@@ -186,6 +186,16 @@ int main(int argc, char** argv) {
                 std::snprintf(nm, sizeof nm, "out mt%d sp%d", mt, sp); bench_skinny(nm, 64, 1024, 1024, sp, mt);
                 std::snprintf(nm, sizeof nm, "ff2 mt%d sp%d", mt, sp); bench_skinny(nm, 64, 1024, 4096, sp, mt);
             }
+    }
+    if (want("skinny_q8_sweep")) {
+        for (int mt : {4, 2, 1}) {
+            char nm[64];
+            std::snprintf(nm, sizeof nm, "q8 qkv mt%d sp1", mt); bench_skinny_q8(nm, 64, 3072, 1024, 1, mt);
+            std::snprintf(nm, sizeof nm, "q8 qkv mt%d sp4", mt); bench_skinny_q8(nm, 64, 3072, 1024, 4, mt);
+            std::snprintf(nm, sizeof nm, "q8 ff1 mt%d sp1", mt); bench_skinny_q8(nm, 64, 4096, 1024, 1, mt);
+            std::snprintf(nm, sizeof nm, "q8 out mt%d sp4", mt); bench_skinny_q8(nm, 64, 1024, 1024, 4, mt);
+            std::snprintf(nm, sizeof nm, "q8 ff2 mt%d sp8", mt); bench_skinny_q8(nm, 64, 1024, 4096, 8, mt);
+        }
     }
     if (want("skinny_ada")) {
         for (int mt : {4, 2, 1})
