@@ -311,13 +311,13 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
     // XCD's L2 after the first: same-column workgroups differ by a multiple of 8 in linear id when grid.x * grid.y
     // is one) and a shorter LDS / MFMA phase per K chunk.
     // Measured at M = 64 (QKV / FFN / output products of the LM step): the time of a launch follows the LDS + MFMA
-    // work per workgroup, not the bytes, until there are about 200 workgroups; 16-row workgroups are 2x faster
+    // work per workgroup, not the bytes, until there are about 500 workgroups; 16-row workgroups are 2x faster
     // than 64-row ones on the unsplit products.
     int mt = a.mtiles;
     if (mt != 1 && mt != 2 && mt != 4) {
         const long long cols = (long long)grid.x * grid.y;
         mt = 4;
-        while (mt > 1 && cols * ((a.M + 16 * mt - 1) / (16 * mt)) < 192) mt >>= 1;
+        while (mt > 1 && cols * ((a.M + 16 * mt - 1) / (16 * mt)) < 512) mt >>= 1;
         if (a.M <= 16 * (mt / 2)) mt = a.M <= 16 ? 1 : 2;     // never stage rows that do not exist
     }
     grid.z = (a.M + 16 * mt - 1) / (16 * mt);

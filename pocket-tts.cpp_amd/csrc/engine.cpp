@@ -181,6 +181,10 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     flow_in_packed = packed("flow.in_proj.w");
     flow_out_packed = packed("flow.final.lin.w");
     flow_cond_packed = packed("flow.cond.w");
+    {
+        const HostTensor& t = pack.get("lm.in_proj.w");
+        if (t.shape[0] % 16 == 0 && t.shape[1] % (flow_wtype == W_BF16 ? 32 : 16) == 0) lm_in_packed = packed("lm.in_proj.w");
+    }
     {   // stacked adaLN matrix in the same fragment-major form (the skinny product is 2x faster than the tiled GEMM here)
         const int kstep = flow_wtype == W_BF16 ? 32 : 16;
         if (mod_width % 16 == 0 && C % kstep == 0) {
@@ -776,11 +780,18 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
     const int B = b.B, D = s.d_model, F = s.lm_ffn;
     const int wt = model_->lm_wtype, kstep = wt == W_I8 ? 64 : wt == W_BF16 ? 32 : 16;
     launch_prep_latent(seq_dev, b.seq_in.f(), B, s.latent, 0, hd_.bos, nullptr, b.st);
-    const DevWeight& win = hd_.lm_in;
-    GemmArgs g;
-    g.A = b.seq_in.f(); g.lda = s.latent; g.W = win.p; g.wtype = win.wtype; g.C = b.x.f(); g.ldc = D;
-    g.M = B; g.N = D; g.K = s.latent; g.split_a = 1;
-    launch_gemm(g, b.st);
+    if (model_->lm_in_packed && s.latent % 4 == 0) {
+        SkinnyArgs g;
+        g.A = b.seq_in.f(); g.lda = s.latent; g.Wp = model_->lm_in_packed; g.wtype = model_->flow_wtype; g.M = B; g.N = D; g.K = s.latent;
+        g.C = b.x.f(); g.ldc = D;
+        launch_skinny_gemm(g, b.st);
+    } else {
+        const DevWeight& win = hd_.lm_in;
+        GemmArgs g;
+        g.A = b.seq_in.f(); g.lda = s.latent; g.W = win.p; g.wtype = win.wtype; g.C = b.x.f(); g.ldc = D;
+        g.M = B; g.N = D; g.K = s.latent; g.split_a = 1;
+        launch_gemm(g, b.st);
+    }
     const int s_out = pick_splits(D, kstep), s_ff2 = pick_splits(F, kstep);
     int s_qkv = 1;
     if (const char* e = std::getenv("POCKET_TTS_QKV_SPLITS")) s_qkv = std::atoi(e);

@@ -58,6 +58,7 @@ public:
     int flow_block_wtype = W_F32;
     std::vector<PackedLayer> lm_packed;
     const void* flow_cond_packed = nullptr;
+    const void* lm_in_packed = nullptr;  // LM input projection, fragment-major (null when its shape does not tile)
     const void* ada_packed = nullptr;   // stacked adaLN matrix, fragment-major (null when its shape does not tile)
     int flow_wtype = W_F32;
 
