@@ -50,10 +50,21 @@ template <> struct FlowTraits<__bf16> { static constexpr int pad = 8, kstep = 32
 
 __device__ __forceinline__ float silu_dev(float v) { return v / (1.0f + expf(-v)); }
 
+// Sum over the 64 lanes, the same value in every lane.  Four DPP steps (swap within pairs, swap pairs within
+// quads, mirror each half row, mirror the row) leave each 16-lane row's sum in all of its lanes; the four row sums
+// are then read as scalars.  About a fifth of the latency of six ds_bpermute butterflies.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // acc += A[16][k0 .. k0+kstep) * fragment, A in LDS (plane 0 = value or hi term, plane 1 = lo term)
@@ -112,13 +123,17 @@ template <int C> struct RowMap {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
 
-// h = h_prev + gate * (part[0] + part[1] + ... + part[G-1] + bias), partials added in index order
+// h = h_prev + gate * (part[0] + part[1] + ... + part[G-1] + bias), partials added in index order.
+// The operands are requested by residual_load and consumed by residual_finish, so that a kernel can put other
+// loads (its weight stream) behind them: vmcnt retires in issue order, and what is needed first must be asked first.
+template <int C, int G> struct ResRegs {
+    float4 hv[2][RowMap<C>::NP], gt[2][RowMap<C>::NP], bs[RowMap<C>::NP], pt[G][2][RowMap<C>::NP];
+};
+
 template <int C, int G>
-__device__ __forceinline__ void residual_update(float4 (&h)[2][RowMap<C>::NP], const float* h_prev, const float* part, long long part_gs,
-                                                const float* gate_base, int mod_width, const float* bias, int row0, int nrows,
-                                                int wave, int lane) {
+__device__ __forceinline__ void residual_load(ResRegs<C, G>& r, const float* h_prev, const float* part, long long part_gs, const float* gate_base,
+                                              int mod_width, const float* bias, int row0, int nrows, int wave, int lane) {
     using RM = RowMap<C>;
-    float4 hv[2][RM::NP], gt[2][RM::NP], bs[RM::NP], pt[G][2][RM::NP];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int lr = 2 * wave + rr;
@@ -126,50 +141,73 @@ __device__ __forceinline__ void residual_update(float4 (&h)[2][RowMap<C>::NP], c
 #pragma unroll
         for (int i = 0; i < RM::NP; ++i) {
             const int c = RM::col(lane, i);
-            hv[rr][i] = ld4(h_prev + grow * C + c);
-            gt[rr][i] = ld4(gate_base + grow * mod_width + c);
+            r.hv[rr][i] = ld4(h_prev + grow * C + c);
+            r.gt[rr][i] = ld4(gate_base + grow * mod_width + c);
 #pragma unroll
-            for (int g = 0; g < G; ++g) pt[g][rr][i] = ld4(part + g * part_gs + grow * C + c);
+            for (int g = 0; g < G; ++g) r.pt[g][rr][i] = ld4(part + g * part_gs + grow * C + c);
         }
     }
 #pragma unroll
-    for (int i = 0; i < RM::NP; ++i) bs[i] = ld4(bias + RM::col(lane, i));
+    for (int i = 0; i < RM::NP; ++i) r.bs[i] = ld4(bias + RM::col(lane, i));
+}
+
+template <int C, int G>
+__device__ __forceinline__ void residual_finish(float4 (&h)[2][RowMap<C>::NP], const ResRegs<C, G>& r) {
+    using RM = RowMap<C>;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
         for (int i = 0; i < RM::NP; ++i) {
-            float4 sum = pt[0][rr][i];
+            float4 sum = r.pt[0][rr][i];
 #pragma unroll
-            for (int g = 1; g < G; ++g) { sum.x += pt[g][rr][i].x; sum.y += pt[g][rr][i].y; sum.z += pt[g][rr][i].z; sum.w += pt[g][rr][i].w; }
-            float4 o = hv[rr][i];
-            o.x += gt[rr][i].x * (sum.x + bs[i].x); o.y += gt[rr][i].y * (sum.y + bs[i].y);
-            o.z += gt[rr][i].z * (sum.z + bs[i].z); o.w += gt[rr][i].w * (sum.w + bs[i].w);
+            for (int g = 1; g < G; ++g) { sum.x += r.pt[g][rr][i].x; sum.y += r.pt[g][rr][i].y; sum.z += r.pt[g][rr][i].z; sum.w += r.pt[g][rr][i].w; }
+            float4 o = r.hv[rr][i];
+            o.x += r.gt[rr][i].x * (sum.x + r.bs[i].x); o.y += r.gt[rr][i].y * (sum.y + r.bs[i].y);
+            o.z += r.gt[rr][i].z * (sum.z + r.bs[i].z); o.w += r.gt[rr][i].w * (sum.w + r.bs[i].w);
             h[rr][i] = o;
         }
 }
 
-// LayerNorm (optional affine) + adaLN modulate of the wave's two rows -> A-operand planes
-template <typename WT, int C, bool AFFINE>
-__device__ __forceinline__ void norm_modulate(const float4 (&h)[2][RowMap<C>::NP], WT* A0, WT* A1, int lda, const float* ln_g,
-                                              const float* ln_b, const float* shift_base, const float* scale_base, int mod_width,
-                                              float eps, int row0, int nrows, int wave, int lane) {
+template <int C, int G>
+__device__ __forceinline__ void residual_update(float4 (&h)[2][RowMap<C>::NP], const float* h_prev, const float* part, long long part_gs,
+                                                const float* gate_base, int mod_width, const float* bias, int row0, int nrows,
+                                                int wave, int lane) {
+    ResRegs<C, G> r;
+    residual_load<C, G>(r, h_prev, part, part_gs, gate_base, mod_width, bias, row0, nrows, wave, lane);
+    residual_finish<C, G>(h, r);
+}
+
+// adaLN shift / scale rows and LayerNorm affine vectors of the wave's two rows, requested apart from their use.
+template <int C> struct ModRegs {
+    float4 sh[2][RowMap<C>::NP], sc[2][RowMap<C>::NP], g4[RowMap<C>::NP], b4[RowMap<C>::NP];
+};
+
+template <int C, bool AFFINE>
+__device__ __forceinline__ void load_mod(ModRegs<C>& m, const float* ln_g, const float* ln_b, const float* shift_base, const float* scale_base,
+                                         int mod_width, int row0, int nrows, int wave, int lane) {
     using RM = RowMap<C>;
-    float4 sh[2][RM::NP], sc[2][RM::NP], g4[RM::NP], b4[RM::NP];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int lr = 2 * wave + rr;
         const long long grow = row0 + (lr < nrows ? lr : nrows - 1);
 #pragma unroll
         for (int i = 0; i < RM::NP; ++i) {
-            sh[rr][i] = ld4(shift_base + grow * mod_width + RM::col(lane, i));
-            sc[rr][i] = ld4(scale_base + grow * mod_width + RM::col(lane, i));
+            m.sh[rr][i] = ld4(shift_base + grow * mod_width + RM::col(lane, i));
+            m.sc[rr][i] = ld4(scale_base + grow * mod_width + RM::col(lane, i));
         }
     }
 #pragma unroll
     for (int i = 0; i < RM::NP; ++i) {
-        if constexpr (AFFINE) { g4[i] = ld4(ln_g + RM::col(lane, i)); b4[i] = ld4(ln_b + RM::col(lane, i)); }
-        else { g4[i] = make_float4(1.f, 1.f, 1.f, 1.f); b4[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if constexpr (AFFINE) { m.g4[i] = ld4(ln_g + RM::col(lane, i)); m.b4[i] = ld4(ln_b + RM::col(lane, i)); }
+        else { m.g4[i] = make_float4(1.f, 1.f, 1.f, 1.f); m.b4[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
     }
+}
+
+// LayerNorm (affine in m) + adaLN modulate of the wave's two rows -> A-operand planes
+template <typename WT, int C>
+__device__ __forceinline__ void norm_apply(const float4 (&h)[2][RowMap<C>::NP], const ModRegs<C>& m, WT* A0, WT* A1, int lda, float eps,
+                                           int wave, int lane) {
+    using RM = RowMap<C>;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         float s = 0.f;
@@ -189,13 +227,22 @@ __device__ __forceinline__ void norm_modulate(const float4 (&h)[2][RowMap<C>::NP
         for (int i = 0; i < RM::NP; ++i)
             if (RM::valid(lane, i)) {
                 float4 y;
-                y.x = ((h[rr][i].x - mean) * rstd * g4[i].x + b4[i].x) * (1.0f + sc[rr][i].x) + sh[rr][i].x;
-                y.y = ((h[rr][i].y - mean) * rstd * g4[i].y + b4[i].y) * (1.0f + sc[rr][i].y) + sh[rr][i].y;
-                y.z = ((h[rr][i].z - mean) * rstd * g4[i].z + b4[i].z) * (1.0f + sc[rr][i].z) + sh[rr][i].z;
-                y.w = ((h[rr][i].w - mean) * rstd * g4[i].w + b4[i].w) * (1.0f + sc[rr][i].w) + sh[rr][i].w;
+                y.x = ((h[rr][i].x - mean) * rstd * m.g4[i].x + m.b4[i].x) * (1.0f + m.sc[rr][i].x) + m.sh[rr][i].x;
+                y.y = ((h[rr][i].y - mean) * rstd * m.g4[i].y + m.b4[i].y) * (1.0f + m.sc[rr][i].y) + m.sh[rr][i].y;
+                y.z = ((h[rr][i].z - mean) * rstd * m.g4[i].z + m.b4[i].z) * (1.0f + m.sc[rr][i].z) + m.sh[rr][i].z;
+                y.w = ((h[rr][i].w - mean) * rstd * m.g4[i].w + m.b4[i].w) * (1.0f + m.sc[rr][i].w) + m.sh[rr][i].w;
                 put_act4<WT>(A0, A1, (2 * wave + rr) * lda + 4 * (lane + 64 * i), y);
             }
     }
+}
+
+template <typename WT, int C, bool AFFINE>
+__device__ __forceinline__ void norm_modulate(const float4 (&h)[2][RowMap<C>::NP], WT* A0, WT* A1, int lda, const float* ln_g,
+                                              const float* ln_b, const float* shift_base, const float* scale_base, int mod_width,
+                                              float eps, int row0, int nrows, int wave, int lane) {
+    ModRegs<C> m;
+    load_mod<C, AFFINE>(m, ln_g, ln_b, shift_base, scale_base, mod_width, row0, nrows, wave, lane);
+    norm_apply<WT, C>(h, m, A0, A1, lda, eps, wave, lane);
 }
 
 struct FlowBlockArgs {
@@ -211,6 +258,7 @@ struct FlowBlockArgs {
     const float* s1 = nullptr; const float* s2 = nullptr;   // int8 blocks: per-output-column scales of fc1 / fc2
     const float* ln_g = nullptr; const float* ln_b = nullptr;
     int B = 0, mod_width = 0, rpg = 16;   // rpg: utterance rows per workgroup row group (<= 16, the MFMA tile height)
+    long long* cycles = nullptr;          // optional [8]: s_memtime of workgroup (0,0) wave 0 at the phase boundaries (tuning aid)
     float eps = 1e-6f;
 };
 
@@ -241,23 +289,36 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
     const uint4* w1p = (const uint4*)a.w1 + ((long long)g * NT1 * KS) * 64 + lane;   // + (t*KS + ks)*64
     const uint4* w2p = (const uint4*)a.w2 + ((long long)g * KS2) * 64 + lane;         // + (t*KS + ks2)*64
 
-    uint4 wf1[PF ? T1 : 1][PF ? KS : 1], wf2[PF ? T2 : 1][PF ? KS2 : 1];
-    if constexpr (PF) {
-#pragma unroll
-        for (int i = 0; i < T1; ++i) {
-            const int t = (wave + kFlowWaves * i) < NT1 ? (wave + kFlowWaves * i) : NT1 - 1;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) wf1[i][ks] = w1p[((long long)t * KS + ks) * 64];
-        }
-#pragma unroll
-        for (int i = 0; i < T2; ++i) {
-            const int t = (wave + kFlowWaves * i) < NT ? (wave + kFlowWaves * i) : NT - 1;
-#pragma unroll
-            for (int ks = 0; ks < KS2; ++ks) wf2[i][ks] = w2p[((long long)t * KS + ks) * 64];
-        }
+    if (a.cycles && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.cycles[0] = __builtin_readcyclecounter();
+    // Order of requests = order of need (vmcnt retires in issue order): the adaLN vectors and the residual operands
+    // of the waves that own live rows, then the fc1 fragments, and the fc2 fragments once the residual operands
+    // have left their registers.  Waves whose rows lie past the row group's end skip the row work altogether
+    // (their A rows stay undefined: MFMA rows are independent and those outputs are never stored).
+    const bool live = 2 * wave < nrows;
+    const float* mblk = a.mods + a.blk * 3 * C;
+    ModRegs<C> mr;
+    ResRegs<C, G> rres;
+    constexpr bool EARLY = C <= 512;   // wider heads do not have the registers to hold everything at once
+    if (live) {
+        if constexpr (EARLY) load_mod<C, true>(mr, a.ln_g, a.ln_b, mblk, mblk + C, a.mod_width, row0, nrows, wave, lane);
+        if (!a.first)
+            residual_load<C, G>(rres, a.h_prev, a.part_prev, (long long)a.B * C, a.mods + (a.blk - 1) * 3 * C + 2 * C, a.mod_width, a.prev_b2,
+                                row0, nrows, wave, lane);
     }
-
-    float bias1[T1];   // fc1 bias of this lane's output columns, requested with the weights
+    uint4 wf1[PF ? T1 : 1][PF ? KS : 1], wf2[PF ? T2 : 1][PF ? KS2 : 1];
+    // fc1 fragments in two halves: the first behind the row operands, the second once those have been consumed
+    auto request_fc1 = [&](int half) {
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < T1; ++i) {
+                const int t = (wave + kFlowWaves * i) < NT1 ? (wave + kFlowWaves * i) : NT1 - 1;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    if ((ks >= KS / 2) == (half != 0)) wf1[i][ks] = w1p[((long long)t * KS + ks) * 64];
+            }
+        }
+    };
+    float bias1[T1];   // fc1 bias of this lane's output columns
 #pragma unroll
     for (int i = 0; i < T1; ++i) {
         const int t = (wave + kFlowWaves * i) < NT1 ? (wave + kFlowWaves * i) : NT1 - 1;
@@ -283,6 +344,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
             for (int ks = 0; ks < KSL; ++ks) wi[i][ks] = ((const uint4*)a.w_in)[((long long)t * KSL + ks) * 64 + lane];
             bin[i] = a.b_in[t * 16 + ccol];
         }
+        request_fc1(0);
 #pragma unroll
         for (int i = 0; i < T2; ++i) {
             const int t = wave + kFlowWaves * i;
@@ -296,25 +358,41 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
             }
         }
         __syncthreads();
+        if (live) {
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
+            for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-            for (int i = 0; i < RM::NP; ++i) h[rr][i] = ld4(hbuf + (2 * wave + rr) * C + RM::col(lane, i));
+                for (int i = 0; i < RM::NP; ++i) h[rr][i] = ld4(hbuf + (2 * wave + rr) * C + RM::col(lane, i));
+        }
     } else {
-        residual_update<C, G>(h, a.h_prev, a.part_prev, (long long)a.B * C, a.mods + (a.blk - 1) * 3 * C + 2 * C, a.mod_width, a.prev_b2,
-                              row0, nrows, wave, lane);
+        request_fc1(0);
+        if (live) residual_finish<C, G>(h, rres);
     }
-    if (g == 0) {   // one workgroup of the row group keeps the stream for the next launch
+    request_fc1(1);
+    if (a.cycles && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.cycles[1] = __builtin_readcyclecounter();
+    if constexpr (PF) {
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
+        for (int i = 0; i < T2; ++i) {
+            const int t = (wave + kFlowWaves * i) < NT ? (wave + kFlowWaves * i) : NT - 1;
 #pragma unroll
-            for (int i = 0; i < RM::NP; ++i)
-                if (2 * wave + rr < nrows && RM::valid(lane, i))
-                    *(float4*)(a.h_next + (long long)(row0 + 2 * wave + rr) * C + 4 * (lane + 64 * i)) = h[rr][i];
+            for (int ks = 0; ks < KS2; ++ks) wf2[i][ks] = w2p[((long long)t * KS + ks) * 64];
+        }
     }
-    const float* mblk = a.mods + a.blk * 3 * C;
-    norm_modulate<WT, C, true>(h, A0, A1, lda, a.ln_g, a.ln_b, mblk, mblk + C, a.mod_width, a.eps, row0, nrows, wave, lane);
+    if (live) {
+        if (g == 0) {   // one workgroup of the row group keeps the stream for the next launch
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int i = 0; i < RM::NP; ++i)
+                    if (2 * wave + rr < nrows && RM::valid(lane, i))
+                        *(float4*)(a.h_next + (long long)(row0 + 2 * wave + rr) * C + 4 * (lane + 64 * i)) = h[rr][i];
+        }
+        if constexpr (!EARLY) load_mod<C, true>(mr, a.ln_g, a.ln_b, mblk, mblk + C, a.mod_width, row0, nrows, wave, lane);
+        norm_apply<WT, C>(h, mr, A0, A1, lda, a.eps, wave, lane);
+    }
+    if (a.cycles && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.cycles[2] = __builtin_readcyclecounter();
     __syncthreads();
+    if (a.cycles && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.cycles[3] = __builtin_readcyclecounter();
 
     // ---- fc1: this workgroup's column slice, full K
 #pragma unroll
@@ -335,7 +413,9 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
             for (int r = 0; r < 4; ++r) put_act<WT>(S0, S1, (crow + r) * lda2 + cl, silu_dev(acc[r] + bias1[i]));
         }
     }
+    if (a.cycles && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.cycles[4] = __builtin_readcyclecounter();
     __syncthreads();
+    if (a.cycles && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.cycles[5] = __builtin_readcyclecounter();
 
     // ---- fc2: every output column, this workgroup's K-slice -> partial
     float* pout = a.part_next + ((long long)g * a.B + row0) * C;
@@ -358,6 +438,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
                 if (crow + r < nrows) pout[(long long)(crow + r) * C + c] = acc[r];
         }
     }
+    if (a.cycles && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.cycles[6] = __builtin_readcyclecounter();
 }
 
 // ---- int8 residual block (v_mfma_i32_16x16x64_i8) ---------------------------------------------------------------
@@ -725,6 +806,7 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
             fb.ln_g = tabs.ln_g[blk]; fb.ln_b = tabs.ln_b[blk];
             if (q8) { fb.s1 = tabs.s_fc1[blk]; fb.s2 = tabs.s_fc2[blk]; }
             fb.B = B; fb.mod_width = a.mod_width; fb.eps = a.eps; fb.rpg = rpg;
+            if (a.cycle_probe && j == 1 && blk == 2) fb.cycles = a.cycle_probe;
             if (q8) hipLaunchKernelGGL(kq, dim3(G, RG), dim3(kFlowThreads), smem_q8, s, fb);
             else hipLaunchKernelGGL(kb, dim3(G, RG), dim3(kFlowThreads), smem_block, s, fb);
             cur ^= 1;

@@ -128,6 +128,7 @@ struct FlowHeadArgs {
     int wtype = W_F32;            // of w_in / w_out
     int block_wtype = -1;         // of the residual blocks' fc1 / fc2 (-1: same as wtype; W_I8: int8 blocks)
     float eps = 1e-6f;
+    long long* cycle_probe = nullptr;   // optional device [8]: cycle counter at the phase boundaries of one mid-chain block launch
 };
 void launch_flow_head(const FlowHeadArgs& a, hipStream_t s);
 size_t flow_head_workspace_bytes(int B, int C, int wtype);

@@ -134,6 +134,14 @@ static void bench_flow(int B) {
     flow_head_prepare(C, W_BF16);
     const double us = time_it("flow_chain", 30, [&](hipStream_t s) { launch_flow_head(a, s); }, 0, 2.0 * B * steps * (2.0 * L * C + nb * 2.0 * C * C));
     std::printf("   = %.2f us per launch over %d launches\n", us / (steps * (nb + 1)), steps * (nb + 1));
+    long long* cyc = (long long*)dalloc(64, 0);
+    a.cycle_probe = cyc;
+    launch_flow_head(a, 0);
+    CK(hipDeviceSynchronize());
+    long long h[8];
+    CK(hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost));
+    std::printf("   cycles: loads-issued->residual %lld, norm %lld, sync %lld, fc1 %lld, sync %lld, fc2+store %lld, total %lld\n", h[1] - h[0], h[2] - h[1],
+                h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
 }
 
 static void bench_attn_decode(int ctx, int kv16) {
