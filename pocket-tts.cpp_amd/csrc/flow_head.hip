@@ -112,7 +112,8 @@ __device__ __forceinline__ void put_act4(WT* A0, WT* A1, int idx, const float4 v
     }
 }
 
-// Row mapping of the element-wise phases: wave w owns rows 2w and 2w+1 of the 16-row group; lane l holds the
+// Row mapping of the element-wise phases: wave w owns rows RPW*w .. RPW*w + RPW-1 of the row group (RPW = 2 covers
+// 16 rows with 8 waves, RPW = 1 serves row groups of up to 8 rows); lane l holds the
 // float4 pieces l, l + 64, ... of each row.  Everything below has compile-time trip counts and no data-dependent
 // branches around loads, so the compiler can put every load of a phase in flight before the first use.
 template <int C> struct RowMap {
@@ -126,17 +127,17 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p
 // h = h_prev + gate * (part[0] + part[1] + ... + part[G-1] + bias), partials added in index order.
 // The operands are requested by residual_load and consumed by residual_finish, so that a kernel can put other
 // loads (its weight stream) behind them: vmcnt retires in issue order, and what is needed first must be asked first.
-template <int C, int G> struct ResRegs {
-    float4 hv[2][RowMap<C>::NP], gt[2][RowMap<C>::NP], bs[RowMap<C>::NP], pt[G][2][RowMap<C>::NP];
+template <int C, int G, int RPW = 2> struct ResRegs {
+    float4 hv[RPW][RowMap<C>::NP], gt[RPW][RowMap<C>::NP], bs[RowMap<C>::NP], pt[G][RPW][RowMap<C>::NP];
 };
 
-template <int C, int G>
-__device__ __forceinline__ void residual_load(ResRegs<C, G>& r, const float* h_prev, const float* part, long long part_gs, const float* gate_base,
+template <int C, int G, int RPW = 2>
+__device__ __forceinline__ void residual_load(ResRegs<C, G, RPW>& r, const float* h_prev, const float* part, long long part_gs, const float* gate_base,
                                               int mod_width, const float* bias, int row0, int nrows, int wave, int lane) {
     using RM = RowMap<C>;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int lr = 2 * wave + rr;
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int lr = RPW * wave + rr;
         const long long grow = row0 + (lr < nrows ? lr : nrows - 1);
 #pragma unroll
         for (int i = 0; i < RM::NP; ++i) {
@@ -151,11 +152,11 @@ __device__ __forceinline__ void residual_load(ResRegs<C, G>& r, const float* h_p
     for (int i = 0; i < RM::NP; ++i) r.bs[i] = ld4(bias + RM::col(lane, i));
 }
 
-template <int C, int G>
-__device__ __forceinline__ void residual_finish(float4 (&h)[2][RowMap<C>::NP], const ResRegs<C, G>& r) {
+template <int C, int G, int RPW = 2>
+__device__ __forceinline__ void residual_finish(float4 (&h)[RPW][RowMap<C>::NP], const ResRegs<C, G, RPW>& r) {
     using RM = RowMap<C>;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr)
+    for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
         for (int i = 0; i < RM::NP; ++i) {
             float4 sum = r.pt[0][rr][i];
@@ -168,27 +169,27 @@ __device__ __forceinline__ void residual_finish(float4 (&h)[2][RowMap<C>::NP], c
         }
 }
 
-template <int C, int G>
-__device__ __forceinline__ void residual_update(float4 (&h)[2][RowMap<C>::NP], const float* h_prev, const float* part, long long part_gs,
+template <int C, int G, int RPW = 2>
+__device__ __forceinline__ void residual_update(float4 (&h)[RPW][RowMap<C>::NP], const float* h_prev, const float* part, long long part_gs,
                                                 const float* gate_base, int mod_width, const float* bias, int row0, int nrows,
                                                 int wave, int lane) {
-    ResRegs<C, G> r;
-    residual_load<C, G>(r, h_prev, part, part_gs, gate_base, mod_width, bias, row0, nrows, wave, lane);
-    residual_finish<C, G>(h, r);
+    ResRegs<C, G, RPW> r;
+    residual_load<C, G, RPW>(r, h_prev, part, part_gs, gate_base, mod_width, bias, row0, nrows, wave, lane);
+    residual_finish<C, G, RPW>(h, r);
 }
 
 // adaLN shift / scale rows and LayerNorm affine vectors of the wave's two rows, requested apart from their use.
-template <int C> struct ModRegs {
-    float4 sh[2][RowMap<C>::NP], sc[2][RowMap<C>::NP], g4[RowMap<C>::NP], b4[RowMap<C>::NP];
+template <int C, int RPW = 2> struct ModRegs {
+    float4 sh[RPW][RowMap<C>::NP], sc[RPW][RowMap<C>::NP], g4[RowMap<C>::NP], b4[RowMap<C>::NP];
 };
 
-template <int C, bool AFFINE>
-__device__ __forceinline__ void load_mod(ModRegs<C>& m, const float* ln_g, const float* ln_b, const float* shift_base, const float* scale_base,
+template <int C, bool AFFINE, int RPW = 2>
+__device__ __forceinline__ void load_mod(ModRegs<C, RPW>& m, const float* ln_g, const float* ln_b, const float* shift_base, const float* scale_base,
                                          int mod_width, int row0, int nrows, int wave, int lane) {
     using RM = RowMap<C>;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int lr = 2 * wave + rr;
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int lr = RPW * wave + rr;
         const long long grow = row0 + (lr < nrows ? lr : nrows - 1);
 #pragma unroll
         for (int i = 0; i < RM::NP; ++i) {
@@ -204,12 +205,12 @@ __device__ __forceinline__ void load_mod(ModRegs<C>& m, const float* ln_g, const
 }
 
 // LayerNorm (affine in m) + adaLN modulate of the wave's two rows -> A-operand planes
-template <typename WT, int C>
-__device__ __forceinline__ void norm_apply(const float4 (&h)[2][RowMap<C>::NP], const ModRegs<C>& m, WT* A0, WT* A1, int lda, float eps,
+template <typename WT, int C, int RPW = 2>
+__device__ __forceinline__ void norm_apply(const float4 (&h)[RPW][RowMap<C>::NP], const ModRegs<C, RPW>& m, WT* A0, WT* A1, int lda, float eps,
                                            int wave, int lane) {
     using RM = RowMap<C>;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
+    for (int rr = 0; rr < RPW; ++rr) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < RM::NP; ++i)
@@ -231,18 +232,18 @@ __device__ __forceinline__ void norm_apply(const float4 (&h)[2][RowMap<C>::NP], 
                 y.y = ((h[rr][i].y - mean) * rstd * m.g4[i].y + m.b4[i].y) * (1.0f + m.sc[rr][i].y) + m.sh[rr][i].y;
                 y.z = ((h[rr][i].z - mean) * rstd * m.g4[i].z + m.b4[i].z) * (1.0f + m.sc[rr][i].z) + m.sh[rr][i].z;
                 y.w = ((h[rr][i].w - mean) * rstd * m.g4[i].w + m.b4[i].w) * (1.0f + m.sc[rr][i].w) + m.sh[rr][i].w;
-                put_act4<WT>(A0, A1, (2 * wave + rr) * lda + 4 * (lane + 64 * i), y);
+                put_act4<WT>(A0, A1, (RPW * wave + rr) * lda + 4 * (lane + 64 * i), y);
             }
     }
 }
 
-template <typename WT, int C, bool AFFINE>
-__device__ __forceinline__ void norm_modulate(const float4 (&h)[2][RowMap<C>::NP], WT* A0, WT* A1, int lda, const float* ln_g,
+template <typename WT, int C, bool AFFINE, int RPW = 2>
+__device__ __forceinline__ void norm_modulate(const float4 (&h)[RPW][RowMap<C>::NP], WT* A0, WT* A1, int lda, const float* ln_g,
                                               const float* ln_b, const float* shift_base, const float* scale_base, int mod_width,
                                               float eps, int row0, int nrows, int wave, int lane) {
-    ModRegs<C> m;
-    load_mod<C, AFFINE>(m, ln_g, ln_b, shift_base, scale_base, mod_width, row0, nrows, wave, lane);
-    norm_apply<WT, C>(h, m, A0, A1, lda, eps, wave, lane);
+    ModRegs<C, RPW> m;
+    load_mod<C, AFFINE, RPW>(m, ln_g, ln_b, shift_base, scale_base, mod_width, row0, nrows, wave, lane);
+    norm_apply<WT, C, RPW>(h, m, A0, A1, lda, eps, wave, lane);
 }
 
 struct FlowBlockArgs {
@@ -264,7 +265,7 @@ struct FlowBlockArgs {
 
 // C = flow_dim, G = column/K split, L = latent_dim; PF: request every weight fragment of the launch up front
 // (needs (C/16/G/8 * C/kstep + C/16/8 * C/kstep/G) * 4 VGPRs, so only for bf16 at C <= 512).
-template <typename WT, int C, int G, int L, bool PF>
+template <typename WT, int C, int G, int L, bool PF, int RPW>
 __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using T = FlowTraits<WT>;
@@ -272,8 +273,14 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
     constexpr int KSTEP = T::kstep, PAD = T::pad, PL = T::planes;
     constexpr int NT = C / 16, NT1 = NT / G, KS = C / KSTEP, KS2 = KS / G, CS = C / G, KSL = L / KSTEP;
     constexpr int lda = C + PAD, lda2 = CS + PAD, ldx = L + PAD;
-    constexpr int T1 = (NT1 + kFlowWaves - 1) / kFlowWaves, T2 = (NT + kFlowWaves - 1) / kFlowWaves;
+    constexpr int T2 = (NT + kFlowWaves - 1) / kFlowWaves;
+    // fc1: K is split over KP1 groups of WPP waves; a wave owns T1 column tiles for its K part and the parts' accumulators
+    // meet in LDS.  Every wave then reads only 1/KP1 of the A operand from LDS (reading all of it in all 8 waves was the
+    // phase's bound) and runs T1 independent MFMA chains.
+    constexpr int KP1 = NT1 >= kFlowWaves ? 2 : kFlowWaves / NT1, WPP = kFlowWaves / KP1, T1 = (NT1 + WPP - 1) / WPP, KSW = KS / KP1;
     static_assert(NT % G == 0 && KS % G == 0 && L % KSTEP == 0, "flow head: split does not tile");
+    static_assert(kFlowWaves % KP1 == 0 && KS % KP1 == 0 && (size_t)kFlowWaves * T1 * 256 <= (size_t)16 * C, "flow head: fc1 K split over waves does not tile");
+    static_assert(RPW * kFlowWaves >= 16 || RPW == 1, "flow head: rows per wave");
     float* hbuf = (float*)smem_raw;                         // [16][C]   (first block only)
     WT* A0 = (WT*)(hbuf + 16 * C);                          // [PL][16][lda]
     WT* A1 = A0 + (PL - 1) * 16 * lda;
@@ -294,39 +301,41 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
     // of the waves that own live rows, then the fc1 fragments, and the fc2 fragments once the residual operands
     // have left their registers.  Waves whose rows lie past the row group's end skip the row work altogether
     // (their A rows stay undefined: MFMA rows are independent and those outputs are never stored).
-    const bool live = 2 * wave < nrows;
+    const bool live = RPW * wave < nrows;
     const float* mblk = a.mods + a.blk * 3 * C;
-    ModRegs<C> mr;
-    ResRegs<C, G> rres;
+    ModRegs<C, RPW> mr;
+    ResRegs<C, G, RPW> rres;
     constexpr bool EARLY = C <= 512;   // wider heads do not have the registers to hold everything at once
     if (live) {
-        if constexpr (EARLY) load_mod<C, true>(mr, a.ln_g, a.ln_b, mblk, mblk + C, a.mod_width, row0, nrows, wave, lane);
+        if constexpr (EARLY) load_mod<C, true, RPW>(mr, a.ln_g, a.ln_b, mblk, mblk + C, a.mod_width, row0, nrows, wave, lane);
         if (!a.first)
-            residual_load<C, G>(rres, a.h_prev, a.part_prev, (long long)a.B * C, a.mods + (a.blk - 1) * 3 * C + 2 * C, a.mod_width, a.prev_b2,
+            residual_load<C, G, RPW>(rres, a.h_prev, a.part_prev, (long long)a.B * C, a.mods + (a.blk - 1) * 3 * C + 2 * C, a.mod_width, a.prev_b2,
                                 row0, nrows, wave, lane);
     }
-    uint4 wf1[PF ? T1 : 1][PF ? KS : 1], wf2[PF ? T2 : 1][PF ? KS2 : 1];
+    uint4 wf1[PF ? T1 : 1][PF ? KSW : 1], wf2[PF ? T2 : 1][PF ? KS2 : 1];
+    const int kp1 = wave / WPP;                                // this wave's K part of its fc1 tiles
+    auto fc1_tile = [&](int i) { return (wave % WPP) + WPP * i; };
     // fc1 fragments in two halves: the first behind the row operands, the second once those have been consumed
     auto request_fc1 = [&](int half) {
         if constexpr (PF) {
 #pragma unroll
             for (int i = 0; i < T1; ++i) {
-                const int t = (wave + kFlowWaves * i) < NT1 ? (wave + kFlowWaves * i) : NT1 - 1;
+                const int t = fc1_tile(i) < NT1 ? fc1_tile(i) : NT1 - 1;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    if ((ks >= KS / 2) == (half != 0)) wf1[i][ks] = w1p[((long long)t * KS + ks) * 64];
+                for (int ks = 0; ks < KSW; ++ks)
+                    if ((ks >= KSW / 2) == (half != 0)) wf1[i][ks] = w1p[((long long)t * KS + kp1 * KSW + ks) * 64];
             }
         }
     };
     float bias1[T1];   // fc1 bias of this lane's output columns
 #pragma unroll
     for (int i = 0; i < T1; ++i) {
-        const int t = (wave + kFlowWaves * i) < NT1 ? (wave + kFlowWaves * i) : NT1 - 1;
+        const int t = fc1_tile(i) < NT1 ? fc1_tile(i) : NT1 - 1;
         bias1[i] = a.b1[g * CS + t * 16 + ccol];
     }
 
     // ---- residual stream rows of this wave
-    float4 h[2][RM::NP];
+    float4 h[RPW][RM::NP];
     if (a.first) {
         const float* xin = a.x_in + (a.x_step ? (long long)(*a.x_step) * a.x_step_stride : 0);
         for (int i = tid; i < 16 * L; i += kFlowThreads) {
@@ -360,13 +369,13 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
         __syncthreads();
         if (live) {
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
+            for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-                for (int i = 0; i < RM::NP; ++i) h[rr][i] = ld4(hbuf + (2 * wave + rr) * C + RM::col(lane, i));
+                for (int i = 0; i < RM::NP; ++i) h[rr][i] = ld4(hbuf + (RPW * wave + rr) * C + RM::col(lane, i));
         }
     } else {
         request_fc1(0);
-        if (live) residual_finish<C, G>(h, rres);
+        if (live) residual_finish<C, G, RPW>(h, rres);
     }
     request_fc1(1);
     if (a.cycles && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.cycles[1] = __builtin_readcyclecounter();
@@ -381,36 +390,55 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
     if (live) {
         if (g == 0) {   // one workgroup of the row group keeps the stream for the next launch
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
+            for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
                 for (int i = 0; i < RM::NP; ++i)
-                    if (2 * wave + rr < nrows && RM::valid(lane, i))
-                        *(float4*)(a.h_next + (long long)(row0 + 2 * wave + rr) * C + 4 * (lane + 64 * i)) = h[rr][i];
+                    if (RPW * wave + rr < nrows && RM::valid(lane, i))
+                        *(float4*)(a.h_next + (long long)(row0 + RPW * wave + rr) * C + 4 * (lane + 64 * i)) = h[rr][i];
         }
-        if constexpr (!EARLY) load_mod<C, true>(mr, a.ln_g, a.ln_b, mblk, mblk + C, a.mod_width, row0, nrows, wave, lane);
-        norm_apply<WT, C>(h, mr, A0, A1, lda, a.eps, wave, lane);
+        if constexpr (!EARLY) load_mod<C, true, RPW>(mr, a.ln_g, a.ln_b, mblk, mblk + C, a.mod_width, row0, nrows, wave, lane);
+        norm_apply<WT, C, RPW>(h, mr, A0, A1, lda, a.eps, wave, lane);
     }
     if (a.cycles && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.cycles[2] = __builtin_readcyclecounter();
     __syncthreads();
     if (a.cycles && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.cycles[3] = __builtin_readcyclecounter();
 
-    // ---- fc1: this workgroup's column slice, full K
+    // ---- fc1: this workgroup's column slice; this wave's K part of its tiles
+    float* red = hbuf;   // [waves][T1][256] accumulators of K parts 1..; hbuf has been read by now
+    f32x4 acc1[T1];
 #pragma unroll
-    for (int i = 0; i < T1; ++i) {
-        const int t = wave + kFlowWaves * i;
-        const int tc = t < NT1 ? t : NT1 - 1;
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < T1; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < KSW; ++ks) {
+#pragma unroll
+        for (int i = 0; i < T1; ++i) {
+            const int tc = fc1_tile(i) < NT1 ? fc1_tile(i) : NT1 - 1;
             uint4 w;
             if constexpr (PF) w = wf1[i][ks];
-            else w = w1p[((long long)tc * KS + ks) * 64];
-            mma_frag<WT>(A0, A1, lda, ks * KSTEP, w, acc, lane);
+            else w = w1p[((long long)tc * KS + kp1 * KSW + ks) * 64];
+            mma_frag<WT>(A0, A1, lda, (kp1 * KSW + ks) * KSTEP, w, acc1[i], lane);
         }
-        if (t < NT1) {
-            const int cl = t * 16 + ccol;
+    }
+    if (kp1 > 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) put_act<WT>(S0, S1, (crow + r) * lda2 + cl, silu_dev(acc[r] + bias1[i]));
+        for (int i = 0; i < T1; ++i) *(f32x4*)(red + (wave * T1 + i) * 256 + lane * 4) = acc1[i];
+    }
+    __syncthreads();
+    if (kp1 == 0) {
+#pragma unroll
+        for (int i = 0; i < T1; ++i) {
+            const int t = fc1_tile(i);
+            f32x4 acc = acc1[i];
+#pragma unroll
+            for (int k = 1; k < KP1; ++k) {
+                const f32x4 o = *(const f32x4*)(red + ((k * WPP + wave) * T1 + i) * 256 + lane * 4);
+                acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3];
+            }
+            if (t < NT1) {
+                const int cl = t * 16 + ccol;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) put_act<WT>(S0, S1, (crow + r) * lda2 + cl, silu_dev(acc[r] + bias1[i]));
+            }
         }
     }
     if (a.cycles && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.cycles[4] = __builtin_readcyclecounter();
@@ -663,7 +691,7 @@ struct FlowFinalArgs {
 
 // Last residual update, final adaLN, output projection (K split over the waves, summed through LDS in wave
 // order), x_out = x_in + dt * v.
-template <typename WT, int C, int G, int L>
+template <typename WT, int C, int G, int L, int RPW>
 __global__ __launch_bounds__(kFlowThreads) void flow_final_kernel(FlowFinalArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using T = FlowTraits<WT>;
@@ -679,14 +707,26 @@ __global__ __launch_bounds__(kFlowThreads) void flow_final_kernel(FlowFinalArgs 
     const int row0 = blockIdx.x * a.rpg;
     const int nrows = (a.B - row0) < a.rpg ? (a.B - row0) : a.rpg;
     const int t = wave % NTL, kp = wave / NTL;
+    // row operands first, the projection fragments behind them (vmcnt retires in issue order)
+    const bool live = RPW * wave < nrows;
+    const float* mfin = a.mods + a.blocks * 3 * C;
+    ModRegs<C, RPW> mr;
+    ResRegs<C, G, RPW> rres;
+    constexpr bool EARLY = C <= 512;   // wider heads do not have the registers to hold everything at once
+    if (live) {
+        if constexpr (EARLY) load_mod<C, false, RPW>(mr, nullptr, nullptr, mfin, mfin + C, a.mod_width, row0, nrows, wave, lane);
+        residual_load<C, G, RPW>(rres, a.h_prev, a.part_prev, (long long)a.B * C, a.mods + (a.blocks - 1) * 3 * C + 2 * C, a.mod_width, a.prev_b2,
+                                 row0, nrows, wave, lane);
+    }
     uint4 wo[KSP];
 #pragma unroll
     for (int ks = 0; ks < KSP; ++ks) wo[ks] = ((const uint4*)a.w_out)[((long long)t * KS + kp * KSP + ks) * 64 + lane];
-    float4 h[2][RM::NP];
-    residual_update<C, G>(h, a.h_prev, a.part_prev, (long long)a.B * C, a.mods + (a.blocks - 1) * 3 * C + 2 * C, a.mod_width, a.prev_b2,
-                          row0, nrows, wave, lane);
-    const float* mfin = a.mods + a.blocks * 3 * C;
-    norm_modulate<WT, C, false>(h, A0, A1, lda, nullptr, nullptr, mfin, mfin + C, a.mod_width, a.eps, row0, nrows, wave, lane);
+    if (live) {
+        float4 h[RPW][RM::NP];
+        residual_finish<C, G, RPW>(h, rres);
+        if constexpr (!EARLY) load_mod<C, false, RPW>(mr, nullptr, nullptr, mfin, mfin + C, a.mod_width, row0, nrows, wave, lane);
+        norm_apply<WT, C, RPW>(h, mr, A0, A1, lda, a.eps, wave, lane);
+    }
     __syncthreads();
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -743,7 +783,7 @@ static void flow_head_shape(int C, int B, bool bf, int& G, int& rpg) {
     G = 4; rpg = 16;
     if (bf && C == 512 && B > 4) rpg = 4;   // measured at B = 64: 4 x 16 -> 627 us per chain, 4 x 4 -> 578 us, 8 x any -> 670+ us
     if (const char* e = std::getenv("FLOW_HEAD_SPLIT")) G = std::atoi(e) == 8 && bf && C == 512 ? 8 : 4;
-    if (const char* e = std::getenv("FLOW_HEAD_ROWS")) { const int r = std::atoi(e); if (r == 4 || r == 8 || r == 16) rpg = r; }
+    if (const char* e = std::getenv("FLOW_HEAD_ROWS")) { const int r = std::atoi(e); if (r == 1 || r == 2 || r == 4 || r == 8 || r == 16) rpg = r; }
 }
 
 size_t flow_head_workspace_bytes(int B, int C, int wtype) {
@@ -763,15 +803,16 @@ static void set_lds_limit(const void* kernel, size_t smem) {
         (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-template <typename WT, int C, bool PF, int G = 4>
+template <typename WT, int C, bool PF, int G = 4, int RPW = 2>
 static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
     constexpr int L = 32;
     using T = FlowTraits<WT>;
     const int B = a.B, RG = (B + rpg - 1) / rpg;
     const size_t smem_block = (size_t)16 * C * 4 + (size_t)T::planes * 16 * ((C + T::pad) + (C / G + T::pad) + (L + T::pad)) * sizeof(WT);
     const size_t smem_final = (size_t)T::planes * 16 * (C + T::pad) * sizeof(WT) + (size_t)kFlowWaves * 256 * 4;
-    auto kb = flow_block_kernel<WT, C, G, L, PF>;
-    auto kf = flow_final_kernel<WT, C, G, L>;
+    auto kb = flow_block_kernel<WT, C, G, L, PF, RPW>;
+    auto kf = flow_final_kernel<WT, C, G, L, RPW>;
+    if (rpg > RPW * kFlowWaves) throw std::runtime_error("flow head: row group larger than the waves can cover");
     set_lds_limit((const void*)kb, smem_block);
     set_lds_limit((const void*)kf, smem_final);
     const bool q8 = a.block_wtype == W_I8;
@@ -823,11 +864,11 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
 
 // Raises the dynamic-LDS limit of every kernel variant on the current device; call once per device outside
 // any stream capture.
-template <typename WT, int C, bool PF, int G = 4>
+template <typename WT, int C, bool PF, int G = 4, int RPW = 2>
 static void prepare_chain() {
     constexpr int L = 32;
-    set_lds_limit((const void*)flow_block_kernel<WT, C, G, L, PF>, 128 * 1024);
-    set_lds_limit((const void*)flow_final_kernel<WT, C, G, L>, 128 * 1024);
+    set_lds_limit((const void*)flow_block_kernel<WT, C, G, L, PF, RPW>, 128 * 1024);
+    set_lds_limit((const void*)flow_final_kernel<WT, C, G, L, RPW>, 128 * 1024);
 }
 void flow_head_prepare(int C, int wtype) {
     const bool bf = wtype == W_BF16;
@@ -835,7 +876,7 @@ void flow_head_prepare(int C, int wtype) {
         case 128: bf ? prepare_chain<__bf16, 128, true>() : prepare_chain<float, 128, false>(); break;
         case 256: bf ? prepare_chain<__bf16, 256, true>() : prepare_chain<float, 256, false>(); break;
         case 512:
-            if (bf) { prepare_chain<__bf16, 512, true>(); prepare_chain<__bf16, 512, true, 8>(); }
+            if (bf) { prepare_chain<__bf16, 512, true>(); prepare_chain<__bf16, 512, true, 4, 1>(); prepare_chain<__bf16, 512, true, 8, 1>(); }
             else prepare_chain<float, 512, false>();
             break;
         case 1024: bf ? prepare_chain<__bf16, 1024, false>() : prepare_chain<float, 1024, false>(); break;
@@ -848,13 +889,16 @@ void launch_flow_head(const FlowHeadArgs& a, hipStream_t s) {
     if (a.L != 32 || a.steps <= 0 || a.blocks <= 0) throw std::runtime_error("flow head: latent_dim must be 32");
     if (!a.workspace || !a.host_tabs) throw std::runtime_error("flow head: workspace and host pointer tables are required");
     const bool bf = a.wtype == W_BF16;
+    const bool q8 = a.block_wtype == W_I8;
     int G = 4, rpg = 16;
     flow_head_shape(a.C, a.B, bf, G, rpg);
+    if (rpg < 4 && (q8 || !(bf && a.C == 512))) rpg = 4;   // row groups under 4 rows exist only for the one-row-per-wave bf16 variants
     switch (a.C) {
         case 128: bf ? run_chain<__bf16, 128, true>(a, s, rpg) : run_chain<float, 128, false>(a, s, rpg); break;
         case 256: bf ? run_chain<__bf16, 256, true>(a, s, rpg) : run_chain<float, 256, false>(a, s, rpg); break;
         case 512:
-            if (bf && G == 8) run_chain<__bf16, 512, true, 8>(a, s, rpg);
+            if (bf && !q8 && G == 8 && rpg <= 8) run_chain<__bf16, 512, true, 8, 1>(a, s, rpg);
+            else if (bf && !q8 && rpg <= 8) run_chain<__bf16, 512, true, 4, 1>(a, s, rpg);
             else if (bf) run_chain<__bf16, 512, true>(a, s, rpg);
             else run_chain<float, 512, false>(a, s, rpg);
             break;

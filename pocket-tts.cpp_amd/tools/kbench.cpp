@@ -115,7 +115,7 @@ static void bench_gemm(const char* name, int M, int N, int K, int split_a, int l
 }
 
 static void bench_flow(int B) {
-    const int C = 512, L = 32, nb = 6, steps = 10, mw = nb * 3 * C + 2 * C;
+    const int C = 512, L = 32, nb = std::getenv("KB_FLOW_BLOCKS") ? std::atoi(std::getenv("KB_FLOW_BLOCKS")) : 6, steps = 10, mw = nb * 3 * C + 2 * C;
     FlowHostTabs tabs;
     for (int i = 0; i < nb; ++i) {
         tabs.w_fc1.push_back(packed_weight(C, C, W_BF16));
