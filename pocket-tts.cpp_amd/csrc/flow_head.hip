@@ -493,7 +493,7 @@ __device__ __forceinline__ float q8_absmax16(const float4 v) {
     return m;
 }
 
-template <int C, int G>
+template <int C, int G, int RPW>
 __global__ __launch_bounds__(kFlowThreads) void flow_block_q8_kernel(FlowBlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using RM = RowMap<C>;
@@ -516,6 +516,18 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_q8_kernel(FlowBlockAr
     const uint4* w1p = (const uint4*)a.w1 + ((long long)g * NT1 * KS) * 64 + lane;
     const uint4* w2p = (const uint4*)a.w2 + ((long long)g * KS2) * 64 + lane;
 
+    // row operands first, the weight fragments behind them (vmcnt retires in issue order)
+    const bool live = RPW * wave < nrows;
+    const float* mblk = a.mods + a.blk * 3 * C;
+    ModRegs<C, RPW> mr;
+    ResRegs<C, G, RPW> rres;
+    constexpr bool EARLY = C <= 512;   // wider heads do not have the registers to hold everything at once
+    if (live && EARLY) {
+        load_mod<C, true, RPW>(mr, a.ln_g, a.ln_b, mblk, mblk + C, a.mod_width, row0, nrows, wave, lane);
+        if (!a.first)
+            residual_load<C, G, RPW>(rres, a.h_prev, a.part_prev, (long long)a.B * C, a.mods + (a.blk - 1) * 3 * C + 2 * C, a.mod_width, a.prev_b2,
+                                     row0, nrows, wave, lane);
+    }
     uint4 wf1[T1][KS], wf2[T2][KS2];
     float bias1[T1], sc1[T1], sc2[T2];
 #pragma unroll
@@ -526,15 +538,8 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_q8_kernel(FlowBlockAr
         bias1[i] = a.b1[g * CS + t * 16 + ccol];
         sc1[i] = a.s1[g * CS + t * 16 + ccol];
     }
-#pragma unroll
-    for (int i = 0; i < T2; ++i) {
-        const int t = (wave + kFlowWaves * i) < NT ? (wave + kFlowWaves * i) : NT - 1;
-#pragma unroll
-        for (int ks = 0; ks < KS2; ++ks) wf2[i][ks] = w2p[((long long)t * KS + ks) * 64];
-        sc2[i] = a.s2[t * 16 + ccol];
-    }
 
-    float4 h[2][RM::NP];
+    float4 h[RPW][RM::NP];
     if (a.first) {
         const float* xin = a.x_in + (a.x_step ? (long long)(*a.x_step) * a.x_step_stride : 0);
         for (int i = tid; i < 16 * L; i += kFlowThreads) {
@@ -563,39 +568,37 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_q8_kernel(FlowBlockAr
             }
         }
         __syncthreads();
+        if (live) {
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
+            for (int rr = 0; rr < RPW; ++rr)
 #pragma unroll
-            for (int i = 0; i < RM::NP; ++i) h[rr][i] = ld4(hbuf + (2 * wave + rr) * C + RM::col(lane, i));
-    } else {
-        residual_update<C, G>(h, a.h_prev, a.part_prev, (long long)a.B * C, a.mods + (a.blk - 1) * 3 * C + 2 * C, a.mod_width, a.prev_b2,
-                              row0, nrows, wave, lane);
-    }
-    if (g == 0) {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int i = 0; i < RM::NP; ++i)
-                if (2 * wave + rr < nrows) *(float4*)(a.h_next + (long long)(row0 + 2 * wave + rr) * C + 4 * (lane + 64 * i)) = h[rr][i];
-    }
-    // LayerNorm + adaLN modulate of the wave's two rows, quantised into Aq / dA
-    {
-        const float* mblk = a.mods + a.blk * 3 * C;
-        float4 sh[2][RM::NP], sc[2][RM::NP], g4v[RM::NP], b4v[RM::NP];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int lr = 2 * wave + rr;
-            const long long grow = row0 + (lr < nrows ? lr : nrows - 1);
-#pragma unroll
-            for (int i = 0; i < RM::NP; ++i) {
-                sh[rr][i] = ld4(mblk + grow * a.mod_width + RM::col(lane, i));
-                sc[rr][i] = ld4(mblk + C + grow * a.mod_width + RM::col(lane, i));
-            }
+                for (int i = 0; i < RM::NP; ++i) h[rr][i] = ld4(hbuf + (RPW * wave + rr) * C + RM::col(lane, i));
         }
+    } else if (live) {
+        if constexpr (!EARLY)
+            residual_load<C, G, RPW>(rres, a.h_prev, a.part_prev, (long long)a.B * C, a.mods + (a.blk - 1) * 3 * C + 2 * C, a.mod_width, a.prev_b2,
+                                     row0, nrows, wave, lane);
+        residual_finish<C, G, RPW>(h, rres);
+    }
 #pragma unroll
-        for (int i = 0; i < RM::NP; ++i) { g4v[i] = ld4(a.ln_g + RM::col(lane, i)); b4v[i] = ld4(a.ln_b + RM::col(lane, i)); }
+    for (int i = 0; i < T2; ++i) {
+        const int t = (wave + kFlowWaves * i) < NT ? (wave + kFlowWaves * i) : NT - 1;
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
+        for (int ks = 0; ks < KS2; ++ks) wf2[i][ks] = w2p[((long long)t * KS + ks) * 64];
+        sc2[i] = a.s2[t * 16 + ccol];
+    }
+    if (live) {
+        if (g == 0) {
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+                for (int i = 0; i < RM::NP; ++i)
+                    if (RPW * wave + rr < nrows) *(float4*)(a.h_next + (long long)(row0 + RPW * wave + rr) * C + 4 * (lane + 64 * i)) = h[rr][i];
+        }
+        // LayerNorm + adaLN modulate of the wave's rows, quantised into Aq / dA
+        if constexpr (!EARLY) load_mod<C, true, RPW>(mr, a.ln_g, a.ln_b, mblk, mblk + C, a.mod_width, row0, nrows, wave, lane);
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < RM::NP; ++i) sum += (h[rr][i].x + h[rr][i].y) + (h[rr][i].z + h[rr][i].w);
@@ -610,13 +613,13 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_q8_kernel(FlowBlockAr
 #pragma unroll
             for (int i = 0; i < RM::NP; ++i) {
                 float4 y;
-                y.x = ((h[rr][i].x - mean) * rstd * g4v[i].x + b4v[i].x) * (1.0f + sc[rr][i].x) + sh[rr][i].x;
-                y.y = ((h[rr][i].y - mean) * rstd * g4v[i].y + b4v[i].y) * (1.0f + sc[rr][i].y) + sh[rr][i].y;
-                y.z = ((h[rr][i].z - mean) * rstd * g4v[i].z + b4v[i].z) * (1.0f + sc[rr][i].z) + sh[rr][i].z;
-                y.w = ((h[rr][i].w - mean) * rstd * g4v[i].w + b4v[i].w) * (1.0f + sc[rr][i].w) + sh[rr][i].w;
+                y.x = ((h[rr][i].x - mean) * rstd * mr.g4[i].x + mr.b4[i].x) * (1.0f + mr.sc[rr][i].x) + mr.sh[rr][i].x;
+                y.y = ((h[rr][i].y - mean) * rstd * mr.g4[i].y + mr.b4[i].y) * (1.0f + mr.sc[rr][i].y) + mr.sh[rr][i].y;
+                y.z = ((h[rr][i].z - mean) * rstd * mr.g4[i].z + mr.b4[i].z) * (1.0f + mr.sc[rr][i].z) + mr.sh[rr][i].z;
+                y.w = ((h[rr][i].w - mean) * rstd * mr.g4[i].w + mr.b4[i].w) * (1.0f + mr.sc[rr][i].w) + mr.sh[rr][i].w;
                 const float m = q8_absmax16(y);
                 const float inv = m > 0.f ? 127.0f / m : 0.f;
-                const int piece = lane + 64 * i, lr = 2 * wave + rr;
+                const int piece = lane + 64 * i, lr = RPW * wave + rr;
                 *(unsigned*)(Aq + lr * lda + 4 * piece) = q8_pack4(y, inv);
                 if ((lane & 15) == 0) dA[(piece >> 4) * 16 + lr] = m / 127.0f;
             }
@@ -820,7 +823,7 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
     void (*kq)(FlowBlockArgs) = nullptr;
     if constexpr (std::is_same<WT, __bf16>::value && C % 256 == 0) {
         if (q8) {
-            kq = flow_block_q8_kernel<C, G>;
+            kq = flow_block_q8_kernel<C, G, RPW>;
             smem_q8 = (size_t)16 * C * 4 + (size_t)16 * (C + 16) + (size_t)(C / 64) * 16 * 4 + (size_t)16 * (C / G + 16) + (size_t)(C / 64 / G) * 16 * 4 +
                       (size_t)2 * 16 * (L + 8) * 2;
             set_lds_limit((const void*)kq, smem_q8);
@@ -892,13 +895,13 @@ void launch_flow_head(const FlowHeadArgs& a, hipStream_t s) {
     const bool q8 = a.block_wtype == W_I8;
     int G = 4, rpg = 16;
     flow_head_shape(a.C, a.B, bf, G, rpg);
-    if (rpg < 4 && (q8 || !(bf && a.C == 512))) rpg = 4;   // row groups under 4 rows exist only for the one-row-per-wave bf16 variants
+    if (rpg < 4 && !(bf && a.C == 512)) rpg = 4;   // row groups under 4 rows exist only for the one-row-per-wave bf16 variants
     switch (a.C) {
         case 128: bf ? run_chain<__bf16, 128, true>(a, s, rpg) : run_chain<float, 128, false>(a, s, rpg); break;
         case 256: bf ? run_chain<__bf16, 256, true>(a, s, rpg) : run_chain<float, 256, false>(a, s, rpg); break;
         case 512:
             if (bf && !q8 && G == 8 && rpg <= 8) run_chain<__bf16, 512, true, 8, 1>(a, s, rpg);
-            else if (bf && !q8 && rpg <= 8) run_chain<__bf16, 512, true, 4, 1>(a, s, rpg);
+            else if (bf && rpg <= 8) run_chain<__bf16, 512, true, 4, 1>(a, s, rpg);
             else if (bf) run_chain<__bf16, 512, true>(a, s, rpg);
             else run_chain<float, 512, false>(a, s, rpg);
             break;
