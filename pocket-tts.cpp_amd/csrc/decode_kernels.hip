@@ -36,6 +36,12 @@ template <> struct SkinnyTraits<__bf16> { static constexpr int kstep = 32, per =
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
+// v + (v of the lane the DPP control selects): 0xB1 / 0x4E swap within pairs / quads, 0x141 / 0x140 mirror a half row / row,
+// 0x120 + n rotates the 16-lane row right by n
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 // a -> (hi, lo) with hi + lo == a to ~16 mantissa bits
 __device__ __forceinline__ void split_bf16(const float4 v, bf16x4& hi, bf16x4& lo) {
     hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
@@ -349,10 +355,17 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
 // Thread t owns channels 4t..4t+3 (D <= 1024).  All K-slice loads of a thread are independent 16-byte
 // loads issued together; the slices are then added in slice order, so the sum is bitwise reproducible.
 
+// sum over the 64 lanes, the same value in every lane: four DPP steps give each 16-lane row its sum, the four row
+// sums are read as scalars
 __device__ __forceinline__ float wsum64(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ float block_sum4(float v, float* red, int tid) {
@@ -416,10 +429,16 @@ void launch_add_norm(const AddNormArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------ decode attention, one 4-wave block per (row, head)
 // The earlier keys of the slot are cut into four contiguous ranges, one per wave (the step is latency
-// bound, so more independent loads in flight matter more than work per wave).  Each wave runs a local
-// softmax over its range (lane per key for the scores, then 4 key groups x 16 channel quads for P.V) and
-// leaves (max, sum, unnormalised output) in LDS; wave 0 merges the four and adds the new token, whose
-// rotated key and value never leave registers.  Every wave rotates q itself; wave 0 appends k, v to the cache.
+// bound, so more independent loads in flight matter more than work per wave).  Each wave runs local
+// softmaxes over its range and leaves (max, sum, unnormalised output) partials in LDS; wave 0 merges them and
+// adds the new token, whose rotated key and value never leave registers.  Every wave rotates q itself; wave 0
+// appends k, v to the cache.
+// bf16 cache with at most 64 keys per wave (the batched frame loop): lane (g, c) = (lane / 8, lane % 8) holds channels
+// 8c..8c+7 of keys g, g+8, ...: one 16-byte load per key for K and for V, a wave instruction covering eight whole
+// 128-byte rows, all 16 loads requested before anything waits on q.  Scores are reduced over the 8 channel lanes
+// by DPP, the softmax and P.V stay in registers in that same layout, and each 16-lane row leaves its own partial
+// (16 partials per workgroup), so nothing crosses a DPP row.  Other cases: lane per key for the scores, then
+// 4 key groups x 16 channel quads for P.V, one partial per wave.
 template <bool KV16>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -441,23 +460,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
         const float* rs = row + (long long)s * a.M * 3 * a.d;
         qv += rs[lane]; kv += rs[a.d + lane]; vv += rs[2 * a.d + lane];
     }
-    // bf16 cache, at most 64 keys for this wave: every K and V element the wave needs is requested here, before
-    // anything waits on q, so the step pays one cache round trip instead of three dependent ones.  Out-of-range
-    // keys re-read the wave's last key (their weight is zero below).
-    bf16x8 kreg[8];
-    bf16x4 vreg[16];
+    // fast path: every K and V element the wave needs is requested here.  Out-of-range keys re-read the wave's last
+    // key (their weight is zero below).
+    bf16x8 kreg[8], vreg[8];
     const bool early = KV16 && cnt > 0 && cnt <= 64;
+    const int kg8 = lane >> 3, c8 = lane & 7;
+    const int ni = __builtin_amdgcn_readfirstlane((cnt + 7) >> 3);   // 8-key steps this wave needs
     if constexpr (KV16) {
         if (early) {
-            const int jk = lane < cnt ? lane : cnt - 1;
-            const __bf16* kp = (const __bf16*)a.kcache + cbase + (long long)((j0 + kb + jk) % a.cap) * a.d;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) kreg[i] = *(const bf16x8*)(kp + 8 * i);
+            for (int i = 0; i < 8; ++i)
+                if (i < ni) {   // wave-uniform: whole instructions of out-of-range keys are not issued
+                    const int jk = kg8 + 8 * i < cnt ? kg8 + 8 * i : cnt - 1;
+                    kreg[i] = *(const bf16x8*)((const __bf16*)a.kcache + cbase + (long long)((j0 + kb + jk) % a.cap) * a.d + 8 * c8);
+                }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int jv = kg + 4 * i < cnt ? kg + 4 * i : cnt - 1;
-                vreg[i] = *(const bf16x4*)((const __bf16*)a.vcache + cbase + (long long)((j0 + kb + jv) % a.cap) * a.d + 4 * cq);
-            }
+            for (int i = 0; i < 8; ++i)
+                if (i < ni) {
+                    const int jk = kg8 + 8 * i < cnt ? kg8 + 8 * i : cnt - 1;
+                    vreg[i] = *(const bf16x8*)((const __bf16*)a.vcache + cbase + (long long)((j0 + kb + jk) % a.cap) * a.d + 8 * c8);
+                }
         }
     }
     const float qo = __shfl_xor(qv, 1, 64), ko = __shfl_xor(kv, 1, 64);
@@ -472,7 +494,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     const int scap = max((a.cap / 4 + 8) & ~3, 64);
     float* qs = smem + (long long)w * (64 + scap);
     float* sc = qs + 64;
-    float* comb = smem + 4ll * (64 + scap);   // [4][68]: max, sum, pad, pad, out[64]
+    float* comb = smem + 4ll * (64 + scap);   // [16][68]: max, sum, pad, pad, out[64]; partial 4w + r
     qs[lane] = qr;
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -489,29 +511,41 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     bool done = false;
     if constexpr (KV16) {
         if (early) {
-            // scores: lane = key, q broadcast from LDS
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            const float4 qa = *(const float4*)(qs + 8 * c8), qb = *(const float4*)(qs + 8 * c8 + 4);
+            float sv[8];
+            float mr = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float4 qa = *(const float4*)(qs + 8 * i), qb = *(const float4*)(qs + 8 * i + 4);
+                sv[i] = -INFINITY;
+                if (i >= ni) continue;
                 const bf16x8 k8 = kreg[i];
-                s0 += qa.x * (float)k8[0]; s1 += qa.y * (float)k8[1]; s2 += qa.z * (float)k8[2]; s3 += qa.w * (float)k8[3];
-                s0 += qb.x * (float)k8[4]; s1 += qb.y * (float)k8[5]; s2 += qb.z * (float)k8[6]; s3 += qb.w * (float)k8[7];
+                float d = ((qa.x * (float)k8[0] + qa.y * (float)k8[1]) + (qa.z * (float)k8[2] + qa.w * (float)k8[3])) +
+                          ((qb.x * (float)k8[4] + qb.y * (float)k8[5]) + (qb.z * (float)k8[6] + qb.w * (float)k8[7]));
+                d = dpp_add<0xB1>(d);    // + the other lane of the pair
+                d = dpp_add<0x4E>(d);    // + the other pair of the quad
+                d = dpp_add<0x141>(d);   // + the other quad of the 8 channel lanes
+                sv[i] = kg8 + 8 * i < cnt ? d * 0.125f : -INFINITY;
+                mr = fmaxf(mr, sv[i]);
             }
-            const float sv = lane < cnt ? ((s0 + s1) + (s2 + s3)) * 0.125f : -INFINITY;
-            mx = sv;
+            mr = fmaxf(mr, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mr), 0x128, 0xF, 0xF, true)));   // row_ror:8
+            float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ls = 0.f;
 #pragma unroll
-            for (int of = 32; of > 0; of >>= 1) mx = fmaxf(mx, __shfl_xor(mx, of, 64));
-            const float e = lane < cnt ? expf(sv - mx) : 0.f;
-            sc[lane] = e;
-            sum = wsum64(e);
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < 8; ++i) {
+                if (i >= ni) continue;
+                const float pw = sv[i] == -INFINITY ? 0.f : expf(sv[i] - mr);
+                ls += pw;
+                const bf16x8 v8 = vreg[i];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float pw = sc[kg + 4 * i];      // zero for keys past cnt
-                const bf16x4 v = vreg[i];
-                o.x += pw * (float)v[0]; o.y += pw * (float)v[1]; o.z += pw * (float)v[2]; o.w += pw * (float)v[3];
+                for (int c = 0; c < 8; ++c) o8[c] += pw * (float)v8[c];
+            }
+            ls = dpp_add<0x128>(ls);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o8[c] = dpp_add<0x128>(o8[c]);
+            float* cw = comb + (w * 4 + (lane >> 4)) * 68;
+            if ((lane & 15) == 0) { cw[0] = mr; cw[1] = ls; }
+            if ((lane & 15) < 8) {
+                *(float4*)(cw + 4 + 8 * c8) = make_float4(o8[0], o8[1], o8[2], o8[3]);
+                *(float4*)(cw + 4 + 8 * c8 + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
             }
             done = true;
         }
@@ -568,26 +602,29 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
             const float p0 = sc[j];
             o.x += p0 * v0.x; o.y += p0 * v0.y; o.z += p0 * v0.z; o.w += p0 * v0.w;
         }
+        o.x += __shfl_xor(o.x, 16, 64); o.y += __shfl_xor(o.y, 16, 64); o.z += __shfl_xor(o.z, 16, 64); o.w += __shfl_xor(o.w, 16, 64);
+        o.x += __shfl_xor(o.x, 32, 64); o.y += __shfl_xor(o.y, 32, 64); o.z += __shfl_xor(o.z, 32, 64); o.w += __shfl_xor(o.w, 32, 64);
+        float* cw = comb + (w * 4) * 68;
+        if (lane == 0) { cw[0] = mx; cw[1] = sum; }
+        if (lane >= 1 && lane < 4) { cw[lane * 68] = -INFINITY; cw[lane * 68 + 1] = 0.f; }   // this wave's other three partials: empty
+        if (kg == 0) *(float4*)(cw + 4 + 4 * cq) = o;
     }
-    o.x += __shfl_xor(o.x, 16, 64); o.y += __shfl_xor(o.y, 16, 64); o.z += __shfl_xor(o.z, 16, 64); o.w += __shfl_xor(o.w, 16, 64);
-    o.x += __shfl_xor(o.x, 32, 64); o.y += __shfl_xor(o.y, 32, 64); o.z += __shfl_xor(o.z, 32, 64); o.w += __shfl_xor(o.w, 32, 64);
-    float* cw = comb + w * 68;
-    if (lane == 0) { cw[0] = mx; cw[1] = sum; }
-    if (kg == 0) *(float4*)(cw + 4 + 4 * cq) = o;
     __syncthreads();
     if (w != 0) return;
     // merge: lane e owns channel e again
     const float s_new = wsum64(qr * kr) * 0.125f;
     float M = s_new;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) M = fmaxf(M, comb[i * 68]);
+    for (int i = 0; i < 16; ++i) M = fmaxf(M, comb[i * 68]);
     float tot = expf(s_new - M), acc = tot * vv;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 16; ++i) {
         const float mi = comb[i * 68];
-        const float f = mi == -INFINITY ? 0.f : expf(mi - M);
-        tot += comb[i * 68 + 1] * f;
-        acc += comb[i * 68 + 4 + lane] * f;
+        if (mi != -INFINITY) {   // uniform over the wave; an empty partial's output words are undefined
+            const float f = expf(mi - M);
+            tot += comb[i * 68 + 1] * f;
+            acc += comb[i * 68 + 4 + lane] * f;
+        }
     }
     const float out = acc / tot;
     a.out[(long long)m * a.d + h * 64 + lane] = out;
@@ -597,7 +634,7 @@ void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     if (a.M <= 0) return;
     if (a.d != a.heads * 64) throw std::runtime_error("attention: head dimension must be 64");
     const int scap = std::max((a.cap / 4 + 8) & ~3, 64);
-    const size_t smem = ((size_t)4 * (64 + scap) + 4 * 68) * sizeof(float);
+    const size_t smem = ((size_t)4 * (64 + scap) + 16 * 68) * sizeof(float);
     if (smem > 64 * 1024) throw std::runtime_error("attention: context capacity too large for the LDS score buffer");
     dim3 grid((unsigned)(a.M * a.heads)), block(256);
     if (a.kv16) hipLaunchKernelGGL(attn_decode_kernel<true>, grid, block, smem, s, a);

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG, "libpocket_tts.so")
+LIB_PATH = os.environ.get("POCKET_TTS_LIB") or os.path.join(PKG, "libpocket_tts.so")   # POCKET_TTS_LIB: another build of the library
 
 f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
