@@ -142,6 +142,24 @@ POCKET_TTS_API int ptts_phase_times(PocketTTSHandle handle, double* times_ms, lo
 /* bytes[0..3] = GEMM weight bytes (compute precision) of the LM, the flow head, the decoder, the encoder */
 POCKET_TTS_API int ptts_weight_bytes(PocketTTSHandle handle, unsigned long long* bytes);
 
+/* Weights carried by an ONNX file: graph initializers and Constant-node tensors, read at the protobuf wire level
+ * (no onnx / protobuf dependency).  The reference gives its five .onnx graphs to ONNX Runtime
+ * (src/pocket_tts.cpp:90-113); a converter (pocket-tts.cpp_amd/tools/onnx_to_ptts.py) uses these calls to build the
+ * engine's weight pack from them.  dtype values are onnx.TensorProto.DataType (1 float, 2 uint8, 3 int8, 6 int32,
+ * 7 int64, 10 float16, 11 double, 16 bfloat16).  read_f32 converts any of those to float; dequantize returns
+ * (q - zero_point) * scale for the <base>_quantized / <base>_scale / <base>_zero_point triplets that ONNX Runtime's
+ * quantisation tools write (axis -1: the one axis whose extent equals the number of scales).  Both return the
+ * element count or -1.  Host only: usable without a GPU. */
+POCKET_TTS_API void* ptts_onnx_open(const char* path);
+POCKET_TTS_API void ptts_onnx_close(void* onnx);
+POCKET_TTS_API int ptts_onnx_tensor_count(void* onnx);
+POCKET_TTS_API int ptts_onnx_tensor_info(void* onnx, int index, const char** name, int* dtype, int* rank, long long* dims8);
+POCKET_TTS_API int ptts_onnx_find(void* onnx, const char* name);
+POCKET_TTS_API long long ptts_onnx_read_f32(void* onnx, int index, float* out, long long cap);
+POCKET_TTS_API long long ptts_onnx_dequantize(void* onnx, const char* base, int axis, float* out, long long cap, int* rank, long long* dims8);
+POCKET_TTS_API int ptts_onnx_node_count(void* onnx);
+POCKET_TTS_API int ptts_onnx_node_info(void* onnx, int index, char* op_type, char* inputs, char* outputs, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 
+#include "onnx_reader.h"
 #include "engine.h"
 #include "pocket_tts/audio_utils.hpp"
 #include "pocket_tts/pocket_tts.hpp"
@@ -523,3 +524,95 @@ POCKET_TTS_API int ptts_weight_bytes(PocketTTSHandle handle, unsigned long long*
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ weights inside an ONNX file (host only)
+
+POCKET_TTS_API void* ptts_onnx_open(const char* path) {
+    if (!path) { set_error("Invalid parameters"); return nullptr; }
+    try {
+        return new ptts::OnnxFile(path);
+    } catch (const std::exception& e) {
+        set_error(std::string("Failed to read ONNX file: ") + e.what());
+        return nullptr;
+    }
+}
+
+POCKET_TTS_API void ptts_onnx_close(void* onnx) { delete static_cast<ptts::OnnxFile*>(onnx); }
+
+POCKET_TTS_API int ptts_onnx_tensor_count(void* onnx) {
+    return onnx ? static_cast<int>(static_cast<ptts::OnnxFile*>(onnx)->tensors().size()) : -1;
+}
+
+POCKET_TTS_API int ptts_onnx_tensor_info(void* onnx, int index, const char** name, int* dtype, int* rank, long long* dims8) {
+    if (!onnx) { set_error("Invalid parameters"); return -1; }
+    const auto& ts = static_cast<ptts::OnnxFile*>(onnx)->tensors();
+    if (index < 0 || index >= static_cast<int>(ts.size())) { set_error("ONNX tensor index out of range"); return -1; }
+    const auto& t = ts[index];
+    if (t.dims.size() > 8) { set_error("ONNX tensor rank above 8"); return -1; }
+    if (name) *name = t.name.c_str();
+    if (dtype) *dtype = t.dtype;
+    if (rank) *rank = static_cast<int>(t.dims.size());
+    if (dims8) for (size_t d = 0; d < t.dims.size(); ++d) dims8[d] = t.dims[d];
+    return 0;
+}
+
+POCKET_TTS_API int ptts_onnx_find(void* onnx, const char* name) {
+    if (!onnx || !name) return -1;
+    return static_cast<ptts::OnnxFile*>(onnx)->find(name);
+}
+
+POCKET_TTS_API long long ptts_onnx_read_f32(void* onnx, int index, float* out, long long cap) {
+    if (!onnx || !out) { set_error("Invalid parameters"); return -1; }
+    long long n = -1;
+    guarded("Failed to read ONNX tensor: ", [&] {
+        const auto v = static_cast<ptts::OnnxFile*>(onnx)->read_f32(index);
+        if (static_cast<long long>(v.size()) > cap) throw std::runtime_error("output buffer too small");
+        std::memcpy(out, v.data(), v.size() * 4);
+        n = static_cast<long long>(v.size());
+        return 0;
+    });
+    return n;
+}
+
+POCKET_TTS_API long long ptts_onnx_dequantize(void* onnx, const char* base, int axis, float* out, long long cap, int* rank, long long* dims8) {
+    if (!onnx || !base || !out) { set_error("Invalid parameters"); return -1; }
+    long long n = -1;
+    guarded("Failed to dequantise ONNX tensor: ", [&] {
+        std::vector<int64_t> dims;
+        const auto v = static_cast<ptts::OnnxFile*>(onnx)->dequantize(base, axis, &dims);
+        if (static_cast<long long>(v.size()) > cap) throw std::runtime_error("output buffer too small");
+        if (dims.size() > 8) throw std::runtime_error("rank above 8");
+        std::memcpy(out, v.data(), v.size() * 4);
+        if (rank) *rank = static_cast<int>(dims.size());
+        if (dims8) for (size_t d = 0; d < dims.size(); ++d) dims8[d] = dims[d];
+        n = static_cast<long long>(v.size());
+        return 0;
+    });
+    return n;
+}
+
+POCKET_TTS_API int ptts_onnx_node_count(void* onnx) {
+    return onnx ? static_cast<int>(static_cast<ptts::OnnxFile*>(onnx)->nodes().size()) : -1;
+}
+
+// op type and the comma-joined input / output names of node `index`, written into caller buffers (truncated to cap - 1)
+POCKET_TTS_API int ptts_onnx_node_info(void* onnx, int index, char* op_type, char* inputs, char* outputs, int cap) {
+    if (!onnx || cap <= 0) { set_error("Invalid parameters"); return -1; }
+    const auto& ns = static_cast<ptts::OnnxFile*>(onnx)->nodes();
+    if (index < 0 || index >= static_cast<int>(ns.size())) { set_error("ONNX node index out of range"); return -1; }
+    auto put = [&](char* dst, const std::string& v) {
+        if (!dst) return;
+        const size_t n = std::min(v.size(), static_cast<size_t>(cap - 1));
+        std::memcpy(dst, v.data(), n);
+        dst[n] = 0;
+    };
+    auto join = [](const std::vector<std::string>& v) {
+        std::string o;
+        for (size_t i = 0; i < v.size(); ++i) { if (i) o += ','; o += v[i]; }
+        return o;
+    };
+    put(op_type, ns[index].op_type);
+    put(inputs, join(ns[index].inputs));
+    put(outputs, join(ns[index].outputs));
+    return 0;
+}

@@ -54,6 +54,8 @@ EXT_SYMBOLS = [
     "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_q8_linear",
     "ptts_tokenizer_new", "ptts_tokenizer_free", "ptts_tokenizer_vocab", "ptts_tokenizer_encode",
     "ptts_audio_load_wav", "ptts_audio_save_wav", "ptts_audio_resample", "ptts_audio_normalize",
+    "ptts_onnx_open", "ptts_onnx_close", "ptts_onnx_tensor_count", "ptts_onnx_tensor_info", "ptts_onnx_find",
+    "ptts_onnx_read_f32", "ptts_onnx_dequantize", "ptts_onnx_node_count", "ptts_onnx_node_info",
 ]
 
 _lib = None

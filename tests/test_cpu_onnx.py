@@ -1,0 +1,193 @@
+"""The ONNX weight reader and the .onnx -> .ptts converter (host only).
+
+No real Pocket TTS ONNX file exists offline, so these tests check the reader against files written by
+tests/onnx_writer.py in every storage form an exporter may choose, and the converter by a round trip: a pack is
+exported as five ONNX files (Linear matrices transposed like torch's MatMul export, conv weights in
+[Cout][Cin][k], some matrices int8 with scales), converted back and compared.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pocket-tts.cpp_amd", "tools"))
+
+import onnx_writer as ow
+
+
+@pytest.fixture(scope="module")
+def ponnx():
+    import ptts_onnx
+    return ptts_onnx
+
+
+def test_reader_storage_forms(tmp_path, ponnx):
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((5, 7)).astype(np.float32)
+    b = rng.standard_normal((3, 2, 4)).astype(np.float32)
+    h = rng.standard_normal((6,)).astype(np.float16)
+    i64 = np.array([[1, -2, 3], [40000000000, -5, 6]], np.int64)
+    d = rng.standard_normal((4,)).astype(np.float64)
+    bf = rng.standard_normal((8,)).astype(np.float32)
+    bf_bits = (bf.view(np.uint32) >> 16).astype(np.uint16)
+    ext = rng.standard_normal((9, 3)).astype(np.float32)
+    with open(tmp_path / "weights.bin", "wb") as f:
+        f.write(b"\0" * 64)
+        f.write(ext.tobytes())
+    c = rng.standard_normal((2, 2)).astype(np.float32)
+    inits = [ow.tensor("a_raw", a), ow.tensor("b_typed", b, "typed"), ow.tensor("b_unpacked", b, "typed_unpacked"),
+             ow.tensor("h_raw", h), ow.tensor("h_typed", h, "typed"), ow.tensor("i64_typed", i64, "typed"), ow.tensor("i64_raw", i64),
+             ow.tensor("d_typed", d, "typed"), ow.tensor("bf_raw", bf_bits, dtype_code=16),
+             ow.tensor("ext", ext, "external", ext=("weights.bin", 64, ext.nbytes)),
+             ow.tensor("scalar", np.float32(2.5).reshape(()))]
+    nodes = [ow.node("Constant", [], ["c_out"], "c0", const=ow.tensor("", c)), ow.node("MatMul", ["x", "a_raw"], ["y"], "mm0")]
+    path = str(tmp_path / "m.onnx")
+    open(path, "wb").write(ow.model(inits, nodes))
+    with ponnx.OnnxWeights(path) as w:
+        assert w.info["a_raw"][1:] == ("float32", (5, 7)) and w.info["h_raw"][1] == "float16" and w.info["bf_raw"][1] == "bfloat16"
+        np.testing.assert_array_equal(w.read("a_raw"), a)
+        np.testing.assert_array_equal(w.read("b_typed"), b)
+        np.testing.assert_array_equal(w.read("b_unpacked"), b)
+        np.testing.assert_array_equal(w.read("h_raw"), h.astype(np.float32))
+        np.testing.assert_array_equal(w.read("h_typed"), h.astype(np.float32))
+        np.testing.assert_array_equal(w.read("i64_typed"), i64.astype(np.float32))
+        np.testing.assert_array_equal(w.read("i64_raw"), i64.astype(np.float32))
+        np.testing.assert_array_equal(w.read("d_typed"), d.astype(np.float32))
+        np.testing.assert_array_equal(w.read("bf_raw"), (bf_bits.astype(np.uint32) << 16).view(np.float32))
+        np.testing.assert_array_equal(w.read("ext"), ext)
+        np.testing.assert_array_equal(w.read("c_out"), c)
+        assert w.read("scalar").shape == () and float(w.read("scalar")) == 2.5
+        assert ("MatMul", ["x", "a_raw"], ["y"]) in w.nodes() and w.nodes()[0][0] == "Constant"
+        with pytest.raises(KeyError):
+            w.read("nope")
+
+
+def test_reader_dequantize(tmp_path, ponnx):
+    rng = np.random.default_rng(1)
+    w0 = rng.standard_normal((12, 8)).astype(np.float32)
+    q1, s1, z1 = ow.quantize_per_axis(w0, 1)                    # per column (MatMul B, axis 1), int8 symmetric
+    q2, s2, z2 = ow.quantize_per_axis(w0, 0, unsigned=True)     # per row, uint8 with zero points
+    sq = rng.standard_normal((6, 6)).astype(np.float32)         # square: the axis cannot be told from the shapes
+    q3, s3, z3 = ow.quantize_per_axis(sq, 0)
+    qt = np.clip(np.rint(w0 / 0.05), -127, 127).astype(np.int8)
+    inits = []
+    for base, q, s, z in (("w1", q1, s1, z1), ("w2", q2, s2, z2), ("w3", q3, s3, z3)):
+        inits += [ow.tensor(base + "_quantized", q), ow.tensor(base + "_scale", s), ow.tensor(base + "_zero_point", z)]
+    inits += [ow.tensor("wt_quantized", qt), ow.tensor("wt_scale", np.float32(0.05).reshape(())), ow.tensor("wt_zero_point", np.int8(0).reshape(()))]
+    inits += [ow.tensor("nozp_quantized", q1), ow.tensor("nozp_scale", s1)]
+    path = str(tmp_path / "q.onnx")
+    open(path, "wb").write(ow.model(inits))
+    with ponnx.OnnxWeights(path) as w:
+        np.testing.assert_allclose(w.dequantize("w1"), q1.astype(np.float32) * s1[None, :], rtol=0, atol=0)
+        np.testing.assert_allclose(w.dequantize("w2"), (q2.astype(np.float32) - z2[:, None].astype(np.float32)) * s2[:, None], rtol=0, atol=0)
+        assert np.abs(w.dequantize("w2") - w0).max() <= s2.max() * 0.51 + 1e-6
+        with pytest.raises(RuntimeError, match="which axis"):
+            w.dequantize("w3")
+        np.testing.assert_allclose(w.dequantize("w3", axis=0), q3.astype(np.float32) * s3[:, None], rtol=0, atol=0)
+        np.testing.assert_allclose(w.dequantize("wt"), qt.astype(np.float32) * np.float32(0.05), rtol=0, atol=0)
+        np.testing.assert_allclose(w.dequantize("nozp"), q1.astype(np.float32) * s1[None, :], rtol=0, atol=0)
+
+
+def test_reader_rejects_garbage(tmp_path, ponnx):
+    p = tmp_path / "bad.onnx"
+    p.write_bytes(b"\x3a\xff\xff\xff\x0f" + b"\0" * 10)      # graph field whose length runs past the end
+    with pytest.raises(RuntimeError, match="Failed to read ONNX file"):
+        ponnx.OnnxWeights(str(p))
+    p.write_bytes(b"\x08\x08")                                  # a model with no graph
+    with pytest.raises(RuntimeError, match="no graph"):
+        ponnx.OnnxWeights(str(p))
+    with pytest.raises(RuntimeError):
+        ponnx.OnnxWeights(str(tmp_path / "missing.onnx"))
+
+
+def _graph_of(name):
+    if name.startswith("text."):
+        return "text_conditioner.onnx"
+    if name.startswith("lm."):
+        return "flow_lm_main.onnx"
+    if name.startswith("flow."):
+        return "flow_lm_flow.onnx"
+    if name.startswith("enc."):
+        return "mimi_encoder.onnx"
+    return "mimi_decoder.onnx"
+
+
+def test_converter_round_trip(tmp_path, packs, ponnx):
+    import onnx_to_ptts
+    import ptts_pack as pp
+    path, spec, w = packs["tiny"]
+    table = pp.tensor_table(spec)
+    per_file = {}
+    mapping = {}
+    for name, shape, _ in table:
+        a = w[name]
+        fn = _graph_of(name)
+        ent = {"file": fn, "tensor": "t::" + name}
+        if name.endswith(".w") and a.ndim == 2 and "conv" not in name and name.startswith("lm.l0."):
+            # int8 MatMul weight stored [K][N] with per-column scales, like a dynamically quantised graph
+            q, s, z = ow.quantize_per_axis(np.ascontiguousarray(a.T), 1)
+            per_file.setdefault(fn, []).extend([ow.tensor(ent["tensor"] + "_quantized", q), ow.tensor(ent["tensor"] + "_scale", s),
+                                                ow.tensor(ent["tensor"] + "_zero_point", z)])
+            ent["transpose"] = True
+            ent["axis"] = 1          # square matrices: the axis cannot be told from the shapes
+        elif name.endswith(".w") and a.ndim == 2 and name.startswith(("lm.", "flow.")):
+            per_file.setdefault(fn, []).append(ow.tensor(ent["tensor"], np.ascontiguousarray(a.T)))   # torch MatMul export: [in][out]
+            ent["transpose"] = True
+        elif name in ("dec.conv0.w", "enc.conv0.w"):
+            cout = a.shape[0]
+            k = spec.kernel
+            a3 = np.ascontiguousarray(a.reshape(cout, k, -1).transpose(0, 2, 1))                      # [Cout][Cin][k]
+            per_file.setdefault(fn, []).append(ow.tensor(ent["tensor"], a3, "typed"))
+            ent["conv"] = True
+        else:
+            per_file.setdefault(fn, []).append(ow.tensor(ent["tensor"], a))
+        mapping[name] = ent
+    mdir = tmp_path / "onnx"
+    mdir.mkdir()
+    for fn, inits in per_file.items():
+        (mdir / fn).write_bytes(ow.model(inits))
+    assert sorted(per_file) == sorted(["text_conditioner.onnx", "flow_lm_main.onnx", "flow_lm_flow.onnx", "mimi_encoder.onnx", "mimi_decoder.onnx"])
+    spec_kw = {f: getattr(spec, f) for f in pp.SPEC_INT_FIELDS + pp.SPEC_FLOAT_FIELDS}
+    (tmp_path / "map.json").write_text(json.dumps({"spec": spec_kw, "tensors": mapping}))
+    out = str(tmp_path / "pocket_tts.ptts")
+    onnx_to_ptts.convert(str(mdir), out, str(tmp_path / "map.json"))
+    spec2, w2 = pp.read_pack(out)
+    assert all(getattr(spec2, f) == getattr(spec, f) for f in pp.SPEC_INT_FIELDS)
+    assert all(getattr(spec2, f) == pytest.approx(getattr(spec, f)) for f in pp.SPEC_FLOAT_FIELDS)   # stored as f32
+    for name, _, _ in table:
+        if name.startswith("lm.l0.") and name.endswith(".w") and w[name].ndim == 2:
+            s_max = np.abs(w[name]).max(1) / 127.0                      # int8 round trip: within half a step of each row's scale
+            assert np.all(np.abs(w2[name] - w[name]).max(1) <= s_max * 0.51 + 1e-7), name
+        else:
+            np.testing.assert_array_equal(w2[name], w[name], err_msg=name)
+    # a map that misses tensors is refused with their names
+    (tmp_path / "map2.json").write_text(json.dumps({"spec": spec_kw, "tensors": {k: v for k, v in mapping.items() if not k.startswith("enc.")}}))
+    with pytest.raises(SystemExit, match="no source"):
+        onnx_to_ptts.convert(str(mdir), out, str(tmp_path / "map2.json"))
+
+
+def test_converter_auto_map(tmp_path, packs, ponnx):
+    """Files whose initializers carry the pack's own names convert without a map (2-D matrices may be transposed)."""
+    import onnx_to_ptts
+    import ptts_pack as pp
+    path, spec, w = packs["tiny"]
+    mdir = tmp_path / "onnx"
+    mdir.mkdir()
+    per_file = {}
+    for name, shape, _ in pp.tensor_table(spec):
+        a = w[name]
+        if a.ndim == 2 and a.shape[0] != a.shape[1] and name.startswith("flow."):
+            a = np.ascontiguousarray(a.T)
+        per_file.setdefault(_graph_of(name), []).append(ow.tensor(name, a))
+    for fn, inits in per_file.items():
+        (mdir / fn).write_bytes(ow.model(inits))
+    spec_kw = {f: getattr(spec, f) for f in pp.SPEC_INT_FIELDS + pp.SPEC_FLOAT_FIELDS}
+    (tmp_path / "map.json").write_text(json.dumps({"spec": spec_kw}))
+    out = str(tmp_path / "auto.ptts")
+    onnx_to_ptts.convert(str(mdir), out, str(tmp_path / "map.json"), auto=True)
+    _, w2 = pp.read_pack(out)
+    for name in w:
+        np.testing.assert_array_equal(w2[name], w[name], err_msg=name)
