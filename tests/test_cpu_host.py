@@ -196,3 +196,35 @@ def test_pack_roundtrip_and_seed_stability(tmp_path):
     gold = np.load(os.path.join(GOLD, "tiny_network.npz"))
     crc = zlib.crc32(b"".join(w[k].tobytes() for k in sorted(w)))
     assert crc == int(gold["pack_crc32"][0]), "numpy's PCG64 stream changed: regenerate tests/golden"
+
+
+def test_parity_report_tool(tmp_path):
+    """tools/parity_report.py on hand-made dumps: identical -> ok with infinite SNR; a noisy copy fails the 40 dB bound
+    and a different chunk layout is reported."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "pocket-tts.cpp_amd", "tools"))
+    import parity_report
+    rng = np.random.default_rng(5)
+    pcm = (rng.standard_normal(3840) * 0.2).astype("<f4")
+    voice = rng.standard_normal(2048).astype("<f4")
+
+    def dump(name, p, v, chunks):
+        d = tmp_path / name
+        d.mkdir()
+        p.tofile(d / "pcm.f32"); v.tofile(d / "voice.f32"); p.tofile(d / "stream_pcm.f32")
+        json.dump(dict(text="t", temperature=0.0, lsd_steps=10, max_frames=500, chunk_frames=5, frames=len(p) // 1920, chunks=chunks),
+                  open(d / "meta.json", "w"))
+        return str(d)
+
+    a = dump("a", pcm, voice, [[3840, 1]])
+    b = dump("b", pcm.copy(), voice.copy(), [[3840, 1]])
+    c = dump("c", (pcm + rng.standard_normal(3840).astype("<f4") * 0.02).astype("<f4"), voice, [[1920, 0], [1920, 1]])
+    ok, lines = parity_report.report(a, b)
+    assert ok and "SNR inf" in lines[1]
+    ok, lines = parity_report.report(a, c)
+    assert not ok and lines[-1] == "PARITY FAILED"
+    snr = float(lines[1].split("SNR ")[1].split(" dB")[0])
+    assert 19.0 < snr < 21.0                                                     # 0.2 / 0.02 -> 20 dB
+    ok, _ = parity_report.report(a, c, min_snr=15.0)
+    assert not ok                                                                # chunk layouts still differ
