@@ -547,6 +547,14 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
             hd_.enc_c1_b[i] = m.f(q + "res.c1.b"); hd_.enc_c2_b[i] = m.f(q + "res.c2.b"); hd_.enc_down_b[i] = m.f(q + "down.b");
         }
     }
+    {
+        int c = 8 * s.n_filters;
+        for (int i = 0; i < 3; ++i) {
+            c /= 2;
+            dec_fused_[i] = !std::getenv("POCKET_TTS_NO_FUSED_RESBLOCK") && hd_.dec_c1[i].wtype == hd_.dec_c2[i].wtype &&
+                            resblock_supported(c, s.res_kernel, hd_.dec_c1[i].wtype);
+        }
+    }
     flow_head_prepare(s.flow_dim, model_->flow_wtype);
     flow_te_.alloc(te.size() * 4);
     PTTS_HIP(hipMemcpy(flow_te_.p, te.data(), te.size() * 4, hipMemcpyHostToDevice));
@@ -933,6 +941,21 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
         GemmArgs up;  // transposed conv: rows = input steps, N = r * co output samples x channels
         up.A = prev; up.a_bs = prev_bs; up.lda = c; up.rpb = T; up.W = wu.p; up.wtype = wu.wtype;
         up.bias = hd_.dec_up_b[i]; up.bias_mod = co; up.M = B * T; up.N = r * co; up.K = 2 * c;
+        if (dec_fused_[i]) {
+            // fused residual unit: the up-sampled rows are kept raw, behind the stream's two previous rows, in the
+            // buffer that otherwise holds their ELU; one kernel does ELU -> conv -> ELU -> conv -> + skip -> ELU
+            up.C = b.uebuf[i].f() + static_cast<long long>(rk - 1) * co; up.c_bs = static_cast<long long>(rk - 1 + T2max) * co; up.ldc = r * co;
+            launch_gemm(up, st);
+            ResblockArgs rb;
+            rb.Y = b.uebuf[i].f(); rb.y_bs = up.c_bs;
+            rb.E = b.ebuf[i].f(); rb.e_bs = static_cast<long long>(hn + T2max) * co; rb.e_off = hn;
+            rb.W1 = w1.p; rb.b1 = hd_.dec_c1_b[i]; rb.W2 = w2.p; rb.b2 = hd_.dec_c2_b[i];
+            rb.T = T2; rb.B = B; rb.co = co;
+            launch_resblock(rb, st);
+            prev = b.ebuf[i].f(); prev_bs = rb.e_bs;
+            c = co; T = T2; Tmax = T2max;
+            continue;
+        }
         up.C = b.ubuf[i].f(); up.c_bs = static_cast<long long>(T2max) * co; up.ldc = r * co;
         up.C2 = b.uebuf[i].f() + static_cast<long long>(rk - 1) * co; up.c2_bs = static_cast<long long>(rk - 1 + T2max) * co;
         up.ldc2 = r * co; up.c2_act = ACT_ELU;

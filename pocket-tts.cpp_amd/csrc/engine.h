@@ -221,6 +221,7 @@ private:
     std::vector<hipEvent_t> lane_events_;
     bool lane_shared_decoder_ = false;          // parts > 1: decoder chunks on dec_stream_ instead of the lane's own stream
     int lanes_ = 1;
+    bool dec_fused_[3] = {false, false, false};   // decoder stages whose residual unit runs as one fused kernel
     bool use_graph_ = true;                     // replay each frame as one hipGraph (POCKET_TTS_NO_GRAPH=1: eager launches)
     Job job_;
     // coalescing queue of generate_one

@@ -100,6 +100,19 @@ void launch_conv_from_mono(const float* audio, long long a_bs, const int* len, i
                            const float* bias, float* raw, long long raw_bs, float* elu, long long elu_bs, int B,
                            hipStream_t s);
 
+// Fused residual unit of a SEANet decoder stage (decoder_fused.hip):
+//   E[b][e_off + t][:] = ELU(y_t + W2 . ELU(W1 * ELU(y_{t-2..t}) + b1) + b2),  y_t = Y[b][t + 2][:]
+// Y holds the two previous rows of the stream in front of the chunk's T rows; bf16 weights, 64 or 128 channels.
+struct ResblockArgs {
+    const float* Y = nullptr; long long y_bs = 0;
+    float* E = nullptr; long long e_bs = 0; int e_off = 0;
+    const void* W1 = nullptr; const float* b1 = nullptr;   // [co/2][3*co] (K index = tap*co + ci), bf16
+    const void* W2 = nullptr; const float* b2 = nullptr;   // [co][co/2], bf16
+    int T = 0, B = 0, co = 0;
+};
+bool resblock_supported(int co, int taps, int wtype);
+void launch_resblock(const ResblockArgs& a, hipStream_t s);
+
 // Carry history: for each b, rows [T, T+H) of buf[b] move to rows [0, H)  (row length C floats).
 void launch_shift_history(float* buf, long long bs, int T, int H, int C, int B, hipStream_t s);
 
