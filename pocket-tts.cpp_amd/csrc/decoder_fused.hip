@@ -1,8 +1,9 @@
 // Fused residual unit of the Mimi decoder's SEANet stages (the reference runs it inside the mimi_decoder graph,
 // /root/reference/src/pocket_tts.cpp:454-546):
 //     e = ELU(y + W2 . ELU(W1 * ELU(y) + b1) + b2)          W1: k = 3 causal taps, C -> C/2;  W2: k = 1, C/2 -> C
-// y is the up-sampling convolution's raw output, channels-last rows with the two previous rows of the stream in
-// front.  The late stages are long and thin (1.8 M rows x 64 channels per 15-frame chunk of 64 utterances): as
+// y is the up-sampling convolution's raw output, channels-last bf16 rows with the two previous rows of the stream
+// in front (these stages are HBM traffic and little else, and every consumer rounds to bf16 anyway; e is bf16 too).
+// The late stages are long and thin (1.8 M rows x 64 channels per 15-frame chunk of 64 utterances): as
 // separate GEMM launches they are pure HBM traffic (y twice, ELU(y), the C/2-wide intermediate written and read),
 // so here a workgroup takes 128 consecutive rows of one utterance through both products with the intermediate
 // in LDS: y is read once (and once more from L2 for the skip), e is written once.
@@ -41,16 +42,16 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResblockArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.y, t0 = blockIdx.x * TM;
-    const float* Y = a.Y + (long long)b * a.y_bs;    // row j = data row j - HIST
+    const __bf16* Y = (const __bf16*)a.Y + (long long)b * a.y_bs;    // row j = data row j - HIST
     // ---- stage the tile (rows t0 - 2 .. t0 + TM - 1 of the stream) and the weights
     {
         constexpr int PPR = CO / 4;
         for (int i = tid; i < (TM + HIST) * PPR; i += 256) {
             const int r = i / PPR, p = i % PPR;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t0 + r < a.T + HIST) v = *(const float4*)(Y + (long long)(t0 + r) * CO + 4 * p);
+            bf16x4 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            if (t0 + r < a.T + HIST) v = *(const bf16x4*)(Y + (long long)(t0 + r) * CO + 4 * p);
             bf16x4 e;
-            e[0] = (__bf16)elu_dev(v.x); e[1] = (__bf16)elu_dev(v.y); e[2] = (__bf16)elu_dev(v.z); e[3] = (__bf16)elu_dev(v.w);
+            e[0] = (__bf16)elu_dev((float)v[0]); e[1] = (__bf16)elu_dev((float)v[1]); e[2] = (__bf16)elu_dev((float)v[2]); e[3] = (__bf16)elu_dev((float)v[3]);
             *(bf16x4*)(As + r * LDA + 4 * p) = e;
         }
         constexpr int P1 = TAPS * CO / 8, P2 = CH / 8;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResblockArgs a) {
             acc2[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, d1, acc2[m][1], 0, 0, 0);
         }
     }
-    float* E = a.E + (long long)b * a.e_bs + (long long)a.e_off * CO;
+    __bf16* E = (__bf16*)a.E + (long long)b * a.e_bs + (long long)a.e_off * CO;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int t = t0 + rw + n * 16 + li;
@@ -121,11 +122,11 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResblockArgs a) {
         for (int m = 0; m < MT2; ++m) {
             const int ch = m * 16 + 4 * g4;
             const float4 bb = *(const float4*)(a.b2 + ch);
-            const float4 y4 = *(const float4*)(Y + (long long)(t + HIST) * CO + ch);   // the skip, f32, from L2
-            float4 o;
-            o.x = elu_dev(acc2[m][n][0] + bb.x + y4.x); o.y = elu_dev(acc2[m][n][1] + bb.y + y4.y);
-            o.z = elu_dev(acc2[m][n][2] + bb.z + y4.z); o.w = elu_dev(acc2[m][n][3] + bb.w + y4.w);
-            *(float4*)(E + (long long)t * CO + ch) = o;
+            const bf16x4 y4 = *(const bf16x4*)(Y + (long long)(t + HIST) * CO + ch);   // the skip, from L2
+            bf16x4 o;
+            o[0] = (__bf16)elu_dev(acc2[m][n][0] + bb.x + (float)y4[0]); o[1] = (__bf16)elu_dev(acc2[m][n][1] + bb.y + (float)y4[1]);
+            o[2] = (__bf16)elu_dev(acc2[m][n][2] + bb.z + (float)y4[2]); o[3] = (__bf16)elu_dev(acc2[m][n][3] + bb.w + (float)y4[3]);
+            *(bf16x4*)(E + (long long)t * CO + ch) = o;
         }
     }
 }
@@ -163,7 +164,7 @@ void resblock_prepare() {
 void launch_resblock(const ResblockArgs& a, hipStream_t s) {
     if (a.T <= 0 || a.B <= 0) return;
     if (!resblock_supported(a.co, 3, W_BF16)) throw std::runtime_error("resblock: fused unit supports 64 or 128 channels");
-    if (((uintptr_t)a.Y & 15) || ((uintptr_t)a.E & 15) || ((uintptr_t)a.W1 & 15) || ((uintptr_t)a.W2 & 15) || (a.y_bs & 3) || (a.e_bs & 3))
+    if (((uintptr_t)a.Y & 15) || ((uintptr_t)a.E & 15) || ((uintptr_t)a.W1 & 15) || ((uintptr_t)a.W2 & 15) || (a.y_bs & 7) || (a.e_bs & 7))
         throw std::runtime_error("resblock: operands must be 16-byte aligned");
     if (a.co == 64) launch_one<64>(a, s);
     else launch_one<128>(a, s);

@@ -933,26 +933,29 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
     }
     const float* prev = b.e0buf.f();
     long long prev_bs = static_cast<long long>(1 + T0max) * c;
+    int prev_bf16 = 0;   // the rows of a fused stage are bf16 in memory
     int T = T0, Tmax = T0max;
     for (int i = 0; i < 3; ++i) {
         const int r = s.ratios[i], co = c / 2, T2 = T * r, T2max = Tmax * r, rk = s.res_kernel;
         const int hn = i < 2 ? 1 : s.last_kernel - 1;
         const DevWeight &wu = hd_.dec_up[i], &w1 = hd_.dec_c1[i], &w2 = hd_.dec_c2[i];
         GemmArgs up;  // transposed conv: rows = input steps, N = r * co output samples x channels
-        up.A = prev; up.a_bs = prev_bs; up.lda = c; up.rpb = T; up.W = wu.p; up.wtype = wu.wtype;
+        up.A = prev; up.a_bs = prev_bs; up.lda = c; up.rpb = T; up.W = wu.p; up.wtype = wu.wtype; up.a_bf16 = prev_bf16;
         up.bias = hd_.dec_up_b[i]; up.bias_mod = co; up.M = B * T; up.N = r * co; up.K = 2 * c;
         if (dec_fused_[i]) {
-            // fused residual unit: the up-sampled rows are kept raw, behind the stream's two previous rows, in the
-            // buffer that otherwise holds their ELU; one kernel does ELU -> conv -> ELU -> conv -> + skip -> ELU
-            up.C = b.uebuf[i].f() + static_cast<long long>(rk - 1) * co; up.c_bs = static_cast<long long>(rk - 1 + T2max) * co; up.ldc = r * co;
+            // fused residual unit: the up-sampled rows are kept raw (bf16), behind the stream's two previous rows, in
+            // the buffer that otherwise holds their ELU; one kernel does ELU -> conv -> ELU -> conv -> + skip -> ELU
+            __bf16* ybuf = reinterpret_cast<__bf16*>(b.uebuf[i].p);
+            up.C = reinterpret_cast<float*>(ybuf + static_cast<long long>(rk - 1) * co); up.c_bf16 = 1;
+            up.c_bs = static_cast<long long>(rk - 1 + T2max) * co; up.ldc = r * co;
             launch_gemm(up, st);
             ResblockArgs rb;
-            rb.Y = b.uebuf[i].f(); rb.y_bs = up.c_bs;
-            rb.E = b.ebuf[i].f(); rb.e_bs = static_cast<long long>(hn + T2max) * co; rb.e_off = hn;
+            rb.Y = ybuf; rb.y_bs = up.c_bs;
+            rb.E = b.ebuf[i].p; rb.e_bs = static_cast<long long>(hn + T2max) * co; rb.e_off = hn;
             rb.W1 = w1.p; rb.b1 = hd_.dec_c1_b[i]; rb.W2 = w2.p; rb.b2 = hd_.dec_c2_b[i];
             rb.T = T2; rb.B = B; rb.co = co;
             launch_resblock(rb, st);
-            prev = b.ebuf[i].f(); prev_bs = rb.e_bs;
+            prev = b.ebuf[i].f(); prev_bs = rb.e_bs; prev_bf16 = 1;
             c = co; T = T2; Tmax = T2max;
             continue;
         }
@@ -972,10 +975,10 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
         c2.C = b.ebuf[i].f() + static_cast<long long>(hn) * co; c2.c_bs = static_cast<long long>(hn + T2max) * co; c2.ldc = co;
         c2.c_act = ACT_ELU;
         launch_gemm(c2, st);
-        prev = b.ebuf[i].f(); prev_bs = c2.c_bs;
+        prev = b.ebuf[i].f(); prev_bs = c2.c_bs; prev_bf16 = 0;
         c = co; T = T2; Tmax = T2max;
     }
-    launch_conv_to_mono(prev, prev_bs, T, s.last_kernel * c, c, hd_.dec_final_w, hd_.dec_final_b, audio_dev, audio_bs, B, st);
+    launch_conv_to_mono(prev, prev_bf16, prev_bs, T, s.last_kernel * c, c, hd_.dec_final_w, hd_.dec_final_b, audio_dev, audio_bs, B, st);
     // carry the streaming histories and positions to the next chunk
     launch_shift_history(b.qbuf.f(), static_cast<long long>(1 + kDecChunk) * M, n, 1, M, B, st);
     launch_shift_history(b.ybuf.f(), ybs, T0, H0, M, B, st);
@@ -985,8 +988,10 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
     for (int i = 0; i < 3; ++i) {
         const int co = c / 2, rk = s.res_kernel, hn = i < 2 ? 1 : s.last_kernel - 1;
         T *= s.ratios[i]; Tmax *= s.ratios[i];
-        launch_shift_history(b.uebuf[i].f(), static_cast<long long>(rk - 1 + Tmax) * co, T, rk - 1, co, B, st);
-        launch_shift_history(b.ebuf[i].f(), static_cast<long long>(hn + Tmax) * co, T, hn, co, B, st);
+        // bf16 rows of a fused stage: the same bytes seen as co/2 floats per row
+        const int div = dec_fused_[i] ? 2 : 1;
+        launch_shift_history(b.uebuf[i].f(), static_cast<long long>(rk - 1 + Tmax) * co / div, T, rk - 1, co / div, B, st);
+        launch_shift_history(b.ebuf[i].f(), static_cast<long long>(hn + Tmax) * co / div, T, hn, co / div, B, st);
         c = co;
     }
     launch_advance_pos(b.dec_pos.as<int>(), B, T0, st);

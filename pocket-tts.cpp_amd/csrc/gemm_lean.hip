@@ -1,0 +1,219 @@
+// bf16-weight GEMM for the shapes the Mimi decoder / encoder and the LM prefill are made of (M in the thousands to
+// millions, N and K a few hundred): C[m][n] = epilogue(sum_k act_a(A[m][k]) * W[n][k]) with the epilogue subset
+//   v = acc + bias[n % bias_mod];  v *= colscale[n] * alpha;  v += R[m][n];  dead rows -> 0;  C = c_act(v);  C2 = c2_act(v)
+// At these shapes the K loop is short and the tile's loads and stores are most of the work, so the kernel is built
+// around them: 128 x 128 tile, K in steps of 64 (half the barriers of a 32-deep step), 16-byte global loads, and
+// the MFMA operands swapped (weights as A, activations as B) so that the accumulator holds C transposed: every
+// lane owns four consecutive n of one row m, hence 16-byte bias / residual loads and 16-byte (f32) or 8-byte
+// (bf16) stores, and only two row-address computations per lane.  A rows and C rows may be bf16 in memory.
+// A is rounded to bf16 once while staged (the two-term form stays with the general kernel in gemm.hip).
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+
+#include "kernels.h"
+
+namespace ptts {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+namespace {
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case ACT_SILU: return v / (1.0f + expf(-v));
+        case ACT_ELU: return v > 0.f ? v : expm1f(v);
+        default: return v;
+    }
+}
+
+constexpr int LBM = 128, LBN = 128, LBK = 64, LLD = LBK + 8;
+
+template <bool ABF, bool CBF>
+__global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[LBM * LLD];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[LBN * LLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.x * LBM, n0 = blockIdx.y * LBN;
+    const int M = a.M, N = a.N, K = a.K;
+
+    // ---- staging assignment: A as 16 (f32) or 8 (bf16) pieces per row of a K step, W as 8 pieces per row
+    constexpr int APR = ABF ? 8 : 16, APT = LBM * APR / 256;     // pieces per row, pieces per thread
+    constexpr int AEL = ABF ? 8 : 4;                             // elements per piece
+    const char* aptr[APT];
+    int ak[APT];
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+        const int id = tid + 256 * i, row = id / APR, p = id % APR;
+        const int m = m0 + row;
+        ak[i] = p * AEL;
+        aptr[i] = nullptr;
+        if (m < M) {
+            const long long off = (long long)(m / a.rpb) * a.a_bs + (long long)(m % a.rpb) * a.lda + p * AEL;
+            aptr[i] = (const char*)a.A + off * (ABF ? 2 : 4);
+        }
+    }
+    constexpr int WPT = LBN * 8 / 256;
+    const __bf16* wptr[WPT];
+    int wk[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int id = tid + 256 * i, row = id >> 3, p = id & 7;
+        wk[i] = p * 8;
+        wptr[i] = (n0 + row < N) ? (const __bf16*)a.W + (long long)(n0 + row) * K + p * 8 : nullptr;
+    }
+    uint4 areg[APT], wreg[WPT];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < APT; ++i)
+            areg[i] = (aptr[i] && k0 + ak[i] < K) ? *(const uint4*)(aptr[i] + (long long)k0 * (ABF ? 2 : 4)) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            wreg[i] = (wptr[i] && k0 + wk[i] < K) ? *(const uint4*)(wptr[i] + k0) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int id = tid + 256 * i, row = id / APR, p = id % APR;
+            if constexpr (ABF) {
+                if (a.a_act != ACT_NONE) {
+                    bf16x8 v = __builtin_bit_cast(bf16x8, areg[i]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)act_apply((float)v[e], a.a_act);
+                    *(bf16x8*)&As[row * LLD + p * 8] = v;
+                } else {
+                    *(uint4*)&As[row * LLD + p * 8] = areg[i];
+                }
+            } else {
+                float4 v = __builtin_bit_cast(float4, areg[i]);
+                if (a.a_act != ACT_NONE) {
+                    v.x = act_apply(v.x, a.a_act); v.y = act_apply(v.y, a.a_act); v.z = act_apply(v.z, a.a_act); v.w = act_apply(v.w, a.a_act);
+                }
+                bf16x4 q;
+                q[0] = (__bf16)v.x; q[1] = (__bf16)v.y; q[2] = (__bf16)v.z; q[3] = (__bf16)v.w;
+                *(bf16x4*)&As[row * LLD + p * 4] = q;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, p = id & 7;
+            *(uint4*)&Ws[row * LLD + p * 8] = wreg[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    load_tiles(0);
+    for (int k0 = 0; k0 < K; k0 += LBK) {
+        store_tiles();
+        __syncthreads();
+        if (k0 + LBK < K) load_tiles(k0 + LBK);
+#pragma unroll
+        for (int ks = 0; ks < LBK / 16; ++ks) {
+            bf16x8 af[2], wf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)&As[(wr * 64 + i * 32 + lr) * LLD + ks * 16 + lh * 8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[j] = *(const bf16x8*)&Ws[(wc * 64 + j * 32 + lr) * LLD + ks * 16 + lh * 8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = row m (lr), registers = n: 8 * (r >> 2) + 4 * lh + (r & 3)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wr * 64 + i * 32 + lr;
+        if (m >= M) continue;
+        const int b = m / a.rpb, t = m % a.rpb;
+        const bool dead = a.row_len && t >= a.row_len[b];
+        const long long crow = (long long)b * a.c_bs + (long long)t * a.ldc;
+        const long long c2row = (long long)b * a.c2_bs + (long long)t * a.ldc2;
+        const float* rrow = a.R ? a.R + (long long)b * a.r_bs + (long long)t * a.ldr : nullptr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wc * 64 + j * 32 + 8 * g + 4 * lh;
+                if (n >= N) continue;
+                float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                if (a.bias) {
+                    const float4 bb = *(const float4*)(a.bias + (a.bias_mod ? n % a.bias_mod : n));
+                    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                }
+                if (a.colscale) {
+                    const float4 cs = *(const float4*)(a.colscale + n);
+                    v.x *= cs.x * a.alpha; v.y *= cs.y * a.alpha; v.z *= cs.z * a.alpha; v.w *= cs.w * a.alpha;
+                } else if (a.alpha != 1.0f) {
+                    v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
+                }
+                if (rrow) {
+                    const float4 rr = *(const float4*)(rrow + n);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                if (dead) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.C) {
+                    float4 o = v;
+                    if (a.c_act != ACT_NONE) { o.x = act_apply(o.x, a.c_act); o.y = act_apply(o.y, a.c_act); o.z = act_apply(o.z, a.c_act); o.w = act_apply(o.w, a.c_act); }
+                    if constexpr (CBF) {
+                        bf16x4 q;
+                        q[0] = (__bf16)o.x; q[1] = (__bf16)o.y; q[2] = (__bf16)o.z; q[3] = (__bf16)o.w;
+                        *(bf16x4*)((__bf16*)a.C + crow + n) = q;
+                    } else {
+                        *(float4*)(a.C + crow + n) = o;
+                    }
+                }
+                if (a.C2) {
+                    float4 o = v;
+                    if (a.c2_act != ACT_NONE) { o.x = act_apply(o.x, a.c2_act); o.y = act_apply(o.y, a.c2_act); o.z = act_apply(o.z, a.c2_act); o.w = act_apply(o.w, a.c2_act); }
+                    *(float4*)(a.C2 + c2row + n) = o;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Whether launch_gemm may hand this problem to the lean kernel.
+bool gemm_lean_eligible(const GemmArgs& a) {
+    if (a.wtype != W_BF16 || a.split_a || a.G || a.act_pre != ACT_NONE) return false;
+    // small problems: the 64 x 64 tiles of the general kernel fill the chip better (bf16 rows exist only here)
+    if (!(a.a_bf16 || a.c_bf16) && (a.M < 512 || a.N < 32)) return false;
+    if ((a.N & 3) || (a.K & 7) || (a.ldc & 3) || (a.c_bs & 3)) return false;
+    const int ael = a.a_bf16 ? 8 : 4;
+    if ((a.lda % ael) || (a.a_bs % ael) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15)) return false;
+    if (a.C && ((uintptr_t)a.C & (a.c_bf16 ? 7 : 15))) return false;
+    if (a.C2 && (((uintptr_t)a.C2 & 15) || (a.ldc2 & 3) || (a.c2_bs & 3))) return false;
+    if (a.bias && (((uintptr_t)a.bias & 15) || (a.bias_mod & 3))) return false;
+    if (a.colscale && ((uintptr_t)a.colscale & 15)) return false;
+    if (a.R && (((uintptr_t)a.R & 15) || (a.ldr & 3) || (a.r_bs & 3))) return false;
+    return true;
+}
+
+void launch_gemm_lean(const GemmArgs& a, hipStream_t s) {
+    dim3 grid((a.M + LBM - 1) / LBM, (a.N + LBN - 1) / LBN), block(256);
+    if (a.a_bf16) {
+        if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_lean_kernel<true, false>), grid, block, 0, s, a);
+    } else {
+        if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_lean_kernel<false, false>), grid, block, 0, s, a);
+    }
+}
+
+}  // namespace ptts

@@ -30,6 +30,7 @@ struct GemmArgs {
     int rpb = 1 << 30;
     int M = 0, N = 0, K = 0;
     int a_act = ACT_NONE, act_pre = ACT_NONE;
+    int a_bf16 = 0, c_bf16 = 0;   // A rows / C rows are bf16 in memory (bf16 weights only; strides count elements)
     int split_a = 0;  // bf16 weights only: stage A as hi + lo bf16 terms (two MFMAs per tile) instead of rounding it once
 };
 void launch_gemm(const GemmArgs& a, hipStream_t s);
@@ -91,7 +92,7 @@ void launch_rowdot(const float* X, int ldx, int M, int D, const float* w, const 
 void launch_upsample_dw(const float* q, long long q_bs, int n, int M, int U, const float* w, float* y, int B, hipStream_t s);
 
 // 1-output-channel conv over a contiguous window: out[b][t] = bias + dot(X[b][t .. t+k-1][:], w[k*C])
-void launch_conv_to_mono(const float* X, long long x_bs, int T, int KC, int C, const float* w, const float* bias,
+void launch_conv_to_mono(const void* X, int x_bf16, long long x_bs, int T, int KC, int C, const float* w, const float* bias,
                          float* out, long long out_bs, int B, hipStream_t s);
 
 // 1-input-channel causal conv: X[b][t][co] = bias[co] + sum_tap w[co][tap] * audio[b][t + tap - (k-1)]
@@ -102,10 +103,11 @@ void launch_conv_from_mono(const float* audio, long long a_bs, const int* len, i
 
 // Fused residual unit of a SEANet decoder stage (decoder_fused.hip):
 //   E[b][e_off + t][:] = ELU(y_t + W2 . ELU(W1 * ELU(y_{t-2..t}) + b1) + b2),  y_t = Y[b][t + 2][:]
-// Y holds the two previous rows of the stream in front of the chunk's T rows; bf16 weights, 64 or 128 channels.
+// Y holds the two previous rows of the stream in front of the chunk's T rows; bf16 weights, bf16 Y and E rows,
+// 64 or 128 channels.
 struct ResblockArgs {
-    const float* Y = nullptr; long long y_bs = 0;
-    float* E = nullptr; long long e_bs = 0; int e_off = 0;
+    const void* Y = nullptr; long long y_bs = 0;           // bf16 rows; strides count elements
+    void* E = nullptr; long long e_bs = 0; int e_off = 0;   // bf16 rows
     const void* W1 = nullptr; const float* b1 = nullptr;   // [co/2][3*co] (K index = tap*co + ci), bf16
     const void* W2 = nullptr; const float* b2 = nullptr;   // [co][co/2], bf16
     int T = 0, B = 0, co = 0;

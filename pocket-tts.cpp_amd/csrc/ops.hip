@@ -301,7 +301,8 @@ void launch_upsample_dw(const float* q, long long q_bs, int n, int M, int U, con
 }
 
 // One wave per 64 consecutive outputs; lane t' computes a dot over its contiguous KC-float window.
-__global__ __launch_bounds__(256) void conv_to_mono_kernel(const float* X, long long x_bs, int T, int KC, int C, const float* w,
+template <bool XBF>
+__global__ __launch_bounds__(256) void conv_to_mono_kernel(const void* X, long long x_bs, int T, int KC, int C, const float* w,
                                                            const float* bias, float* out, long long out_bs) {
     extern __shared__ float wsh[];
     for (int i = threadIdx.x; i < KC; i += blockDim.x) wsh[i] = w[i];
@@ -309,19 +310,29 @@ __global__ __launch_bounds__(256) void conv_to_mono_kernel(const float* X, long 
     const int b = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
-    const float* x = X + (long long)b * x_bs + (long long)t * C;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int i = 0; i < KC; i += 4) {
-        float4 v = *(const float4*)(x + i);
-        s0 += v.x * wsh[i]; s1 += v.y * wsh[i + 1]; s2 += v.z * wsh[i + 2]; s3 += v.w * wsh[i + 3];
+    if constexpr (XBF) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_m;
+        const __bf16* x = (const __bf16*)X + (long long)b * x_bs + (long long)t * C;
+        for (int i = 0; i < KC; i += 4) {
+            const bf16x4_m v = *(const bf16x4_m*)(x + i);
+            s0 += (float)v[0] * wsh[i]; s1 += (float)v[1] * wsh[i + 1]; s2 += (float)v[2] * wsh[i + 2]; s3 += (float)v[3] * wsh[i + 3];
+        }
+    } else {
+        const float* x = (const float*)X + (long long)b * x_bs + (long long)t * C;
+        for (int i = 0; i < KC; i += 4) {
+            float4 v = *(const float4*)(x + i);
+            s0 += v.x * wsh[i]; s1 += v.y * wsh[i + 1]; s2 += v.z * wsh[i + 2]; s3 += v.w * wsh[i + 3];
+        }
     }
     out[(long long)b * out_bs + t] = ((s0 + s1) + (s2 + s3)) + bias[0];
 }
-void launch_conv_to_mono(const float* X, long long x_bs, int T, int KC, int C, const float* w, const float* bias,
+void launch_conv_to_mono(const void* X, int x_bf16, long long x_bs, int T, int KC, int C, const float* w, const float* bias,
                          float* out, long long out_bs, int B, hipStream_t s) {
     if (T <= 0 || B <= 0) return;
     if ((KC & 3) || (C & 3) || (x_bs & 3)) throw std::runtime_error("conv_to_mono: channel counts must be multiples of 4");
-    hipLaunchKernelGGL(conv_to_mono_kernel, dim3((T + 255) / 256, B), dim3(256), KC * sizeof(float), s, X, x_bs, T, KC, C, w, bias, out, out_bs);
+    if (x_bf16) hipLaunchKernelGGL(conv_to_mono_kernel<true>, dim3((T + 255) / 256, B), dim3(256), KC * sizeof(float), s, X, x_bs, T, KC, C, w, bias, out, out_bs);
+    else hipLaunchKernelGGL(conv_to_mono_kernel<false>, dim3((T + 255) / 256, B), dim3(256), KC * sizeof(float), s, X, x_bs, T, KC, C, w, bias, out, out_bs);
 }
 
 __global__ __launch_bounds__(256) void conv_from_mono_kernel(const float* audio, long long a_bs, const int* len, int T, int k, int Co,
