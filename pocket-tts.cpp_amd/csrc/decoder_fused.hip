@@ -26,7 +26,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-__device__ __forceinline__ float elu_dev(float v) { return v > 0.f ? v : expm1f(v); }
+// ELU whose results are stored as bf16: exp(v) - 1 by the hardware exponential is accurate to ~1e-7 absolute, far
+// below the bf16 rounding of the value it feeds
+__device__ __forceinline__ float elu_dev(float v) { return v > 0.f ? v : __expf(v) - 1.0f; }
 
 template <int CO>
 __global__ __launch_bounds__(256) void resblock_kernel(ResblockArgs a) {
@@ -41,19 +43,10 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResblockArgs a) {
     __bf16* W2s = W1s + CH * LDW1;                   // [CO][LDW2]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.y, t0 = blockIdx.x * TM;
+    const int b = blockIdx.y;
     const __bf16* Y = (const __bf16*)a.Y + (long long)b * a.y_bs;    // row j = data row j - HIST
-    // ---- stage the tile (rows t0 - 2 .. t0 + TM - 1 of the stream) and the weights
+    // ---- the weights, once per workgroup (they are as large as a tile's data)
     {
-        constexpr int PPR = CO / 4;
-        for (int i = tid; i < (TM + HIST) * PPR; i += 256) {
-            const int r = i / PPR, p = i % PPR;
-            bf16x4 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-            if (t0 + r < a.T + HIST) v = *(const bf16x4*)(Y + (long long)(t0 + r) * CO + 4 * p);
-            bf16x4 e;
-            e[0] = (__bf16)elu_dev((float)v[0]); e[1] = (__bf16)elu_dev((float)v[1]); e[2] = (__bf16)elu_dev((float)v[2]); e[3] = (__bf16)elu_dev((float)v[3]);
-            *(bf16x4*)(As + r * LDA + 4 * p) = e;
-        }
         constexpr int P1 = TAPS * CO / 8, P2 = CH / 8;
         for (int i = tid; i < CH * P1; i += 256) {
             const int r = i / P1, p = i % P1;
@@ -64,9 +57,26 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResblockArgs a) {
             *(uint4*)(W2s + r * LDW2 + 8 * p) = *(const uint4*)((const __bf16*)a.W2 + (long long)r * CH + 8 * p);
         }
     }
-    __syncthreads();
     const int li = lane & 15, g4 = lane >> 4;
     const int rw = w * 32;                            // this wave's first row inside the tile
+    const int ntiles = (a.T + TM - 1) / TM;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int t0 = tile * TM;
+    __syncthreads();                                  // the previous tile's readers of As are done
+    // ---- stage the tile: rows t0 - 2 .. t0 + TM - 1 of the stream, 16 bytes per lane
+    {
+        constexpr int PPR = CO / 8;
+        for (int i = tid; i < (TM + HIST) * PPR; i += 256) {
+            const int r = i / PPR, p = i % PPR;
+            bf16x8 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            if (t0 + r < a.T + HIST) v = *(const bf16x8*)(Y + (long long)(t0 + r) * CO + 8 * p);
+            bf16x8 e;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = (__bf16)elu_dev((float)v[k]);
+            *(bf16x8*)(As + r * LDA + 8 * p) = e;
+        }
+    }
+    __syncthreads();
     // ---- c1: H^T[CH][rows] = W1[CH][3 CO] . A^T
     f32x4 acc1[MT1][2];
 #pragma unroll
@@ -129,6 +139,7 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResblockArgs a) {
             *(bf16x4*)(E + (long long)t * CO + ch) = o;
         }
     }
+    }   // tiles
 }
 
 template <int CO> static size_t resblock_smem() {
@@ -148,7 +159,9 @@ template <int CO> static void launch_one(const ResblockArgs& a, hipStream_t s) {
             hipFuncSetAttribute((const void*)resblock_kernel<CO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             throw std::runtime_error("resblock: cannot raise the dynamic LDS limit");
     }
-    hipLaunchKernelGGL(resblock_kernel<CO>, dim3((a.T + 127) / 128, a.B), dim3(256), smem, s, a);
+    const int ntiles = (a.T + 127) / 128;
+    const int per_wg = ntiles >= 64 ? 8 : 1;          // long streams: a workgroup walks 8 tiles with one copy of the weights
+    hipLaunchKernelGGL(resblock_kernel<CO>, dim3((ntiles + per_wg - 1) / per_wg, a.B), dim3(256), smem, s, a);
 }
 
 bool resblock_supported(int co, int taps, int wtype) { return wtype == W_BF16 && taps == 3 && (co == 64 || co == 128); }

@@ -301,8 +301,7 @@ void launch_upsample_dw(const float* q, long long q_bs, int n, int M, int U, con
 }
 
 // One wave per 64 consecutive outputs; lane t' computes a dot over its contiguous KC-float window.
-template <bool XBF>
-__global__ __launch_bounds__(256) void conv_to_mono_kernel(const void* X, long long x_bs, int T, int KC, int C, const float* w,
+__global__ __launch_bounds__(256) void conv_to_mono_kernel(const float* X, long long x_bs, int T, int KC, int C, const float* w,
                                                            const float* bias, float* out, long long out_bs) {
     extern __shared__ float wsh[];
     for (int i = threadIdx.x; i < KC; i += blockDim.x) wsh[i] = w[i];
@@ -310,29 +309,65 @@ __global__ __launch_bounds__(256) void conv_to_mono_kernel(const void* X, long l
     const int b = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
+    const float* x = X + (long long)b * x_bs + (long long)t * C;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if constexpr (XBF) {
-        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_m;
-        const __bf16* x = (const __bf16*)X + (long long)b * x_bs + (long long)t * C;
-        for (int i = 0; i < KC; i += 4) {
-            const bf16x4_m v = *(const bf16x4_m*)(x + i);
-            s0 += (float)v[0] * wsh[i]; s1 += (float)v[1] * wsh[i + 1]; s2 += (float)v[2] * wsh[i + 2]; s3 += (float)v[3] * wsh[i + 3];
-        }
-    } else {
-        const float* x = (const float*)X + (long long)b * x_bs + (long long)t * C;
-        for (int i = 0; i < KC; i += 4) {
-            float4 v = *(const float4*)(x + i);
-            s0 += v.x * wsh[i]; s1 += v.y * wsh[i + 1]; s2 += v.z * wsh[i + 2]; s3 += v.w * wsh[i + 3];
+    for (int i = 0; i < KC; i += 4) {
+        float4 v = *(const float4*)(x + i);
+        s0 += v.x * wsh[i]; s1 += v.y * wsh[i + 1]; s2 += v.z * wsh[i + 2]; s3 += v.w * wsh[i + 3];
+    }
+    out[(long long)b * out_bs + t] = ((s0 + s1) + (s2 + s3)) + bias[0];
+}
+
+// bf16 rows: a workgroup stages the 256 + k - 1 rows its outputs need into LDS with 16-byte loads (each row is read
+// from memory once instead of k times by k different lanes), then every thread walks its own window.  Row stride
+// C + 8 elements keeps 16 consecutive lanes on distinct banks.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_m;
+__global__ __launch_bounds__(256) void conv_to_mono_bf16_kernel(const __bf16* X, long long x_bs, int T, int KC, int C, const float* w,
+                                                                const float* bias, float* out, long long out_bs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mono_smem[];
+    float* wsh = (float*)mono_smem;                       // [KC]
+    __bf16* xs = (__bf16*)(wsh + KC);                     // [256 + k - 1][C + 8]
+    const int k = KC / C, ld = C + 8, rows = 256 + k - 1, ppr = C / 8;
+    const int b = blockIdx.y, t0 = blockIdx.x * 256;
+    for (int i = threadIdx.x; i < KC; i += 256) wsh[i] = w[i];
+    const __bf16* x = X + (long long)b * x_bs + (long long)t0 * C;
+    for (int i = threadIdx.x; i < rows * ppr; i += 256) {
+        const int r = i / ppr, p = i % ppr;
+        bf16x8_m v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        if (t0 + r < T + k - 1) v = *(const bf16x8_m*)(x + (long long)r * C + 8 * p);
+        *(bf16x8_m*)(xs + r * ld + 8 * p) = v;
+    }
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
+    if (t >= T) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int tap = 0; tap < k; ++tap) {
+        const __bf16* xr = xs + (threadIdx.x + tap) * ld;
+        const float* wr = wsh + tap * C;
+        for (int c = 0; c < C; c += 8) {
+            const bf16x8_m v = *(const bf16x8_m*)(xr + c);
+            const float4 wa = *(const float4*)(wr + c), wb = *(const float4*)(wr + c + 4);
+            s0 += (float)v[0] * wa.x + (float)v[4] * wb.x; s1 += (float)v[1] * wa.y + (float)v[5] * wb.y;
+            s2 += (float)v[2] * wa.z + (float)v[6] * wb.z; s3 += (float)v[3] * wa.w + (float)v[7] * wb.w;
         }
     }
     out[(long long)b * out_bs + t] = ((s0 + s1) + (s2 + s3)) + bias[0];
 }
+
 void launch_conv_to_mono(const void* X, int x_bf16, long long x_bs, int T, int KC, int C, const float* w, const float* bias,
                          float* out, long long out_bs, int B, hipStream_t s) {
     if (T <= 0 || B <= 0) return;
     if ((KC & 3) || (C & 3) || (x_bs & 3)) throw std::runtime_error("conv_to_mono: channel counts must be multiples of 4");
-    if (x_bf16) hipLaunchKernelGGL(conv_to_mono_kernel<true>, dim3((T + 255) / 256, B), dim3(256), KC * sizeof(float), s, X, x_bs, T, KC, C, w, bias, out, out_bs);
-    else hipLaunchKernelGGL(conv_to_mono_kernel<false>, dim3((T + 255) / 256, B), dim3(256), KC * sizeof(float), s, X, x_bs, T, KC, C, w, bias, out, out_bs);
+    if (x_bf16) {
+        if ((C & 7) || (x_bs & 7) || KC % C) throw std::runtime_error("conv_to_mono: bf16 rows need channel counts that are multiples of 8");
+        const size_t smem = (size_t)KC * 4 + (size_t)(256 + KC / C - 1) * (C + 8) * 2;
+        if (smem > 64 * 1024) throw std::runtime_error("conv_to_mono: window too large for LDS");
+        hipLaunchKernelGGL(conv_to_mono_bf16_kernel, dim3((T + 255) / 256, B), dim3(256), smem, s, (const __bf16*)X, x_bs, T, KC, C, w, bias, out,
+                           out_bs);
+    } else {
+        hipLaunchKernelGGL(conv_to_mono_kernel, dim3((T + 255) / 256, B), dim3(256), KC * sizeof(float), s, (const float*)X, x_bs, T, KC, C, w,
+                           bias, out, out_bs);
+    }
 }
 
 __global__ __launch_bounds__(256) void conv_from_mono_kernel(const float* audio, long long a_bs, const int* len, int T, int k, int Co,
