@@ -205,7 +205,15 @@ void launch_gemm_lean(const GemmArgs& a, hipStream_t s);
 
 void launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return;
-    if (a.K > 0 && a.rpb > 0 && gemm_lean_eligible(a)) { launch_gemm_lean(a, s); return; }
+    if (a.K > 0 && a.rpb > 0) {
+        GemmArgs l = a;
+        // an activation before an otherwise empty epilogue tail is the same as one on the stored value
+        if (l.act_pre != ACT_NONE && !l.G && !l.colscale && l.alpha == 1.0f && !l.R && l.c_act == ACT_NONE && !l.C2) {
+            l.c_act = l.act_pre;
+            l.act_pre = ACT_NONE;
+        }
+        if (gemm_lean_eligible(l)) { launch_gemm_lean(l, s); return; }
+    }
     if (a.a_bf16 || a.c_bf16) throw std::runtime_error("gemm: bf16 activation rows are only handled by the lean kernel (shape or options not eligible)");
     if (a.K <= 0 || (a.K & 3) || (a.lda & 3) || (a.a_bs & 3) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15))
         throw std::runtime_error("gemm: K, lda and batch stride must be multiples of 4 floats and pointers 16-byte aligned");
