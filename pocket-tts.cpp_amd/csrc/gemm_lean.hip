@@ -6,7 +6,7 @@
 // the MFMA operands swapped (weights as A, activations as B) so that the accumulator holds C transposed: every
 // lane owns four consecutive n of one row m, hence 16-byte bias / residual loads and 16-byte (f32) or 8-byte
 // (bf16) stores, and only two row-address computations per lane.  A rows and C rows may be bf16 in memory.
-// A is rounded to bf16 once while staged (the two-term form stays with the general kernel in gemm.hip).
+// A is rounded to bf16 once while staged, or (SPLIT) carried as two bf16 terms.
 #include <hip/hip_runtime.h>
 
 #include <stdexcept>
@@ -32,9 +32,12 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 
 constexpr int LBM = 128, LBN = 128, LBK = 64, LLD = LBK + 8;
 
-template <bool ABF, bool CBF>
+// SPLIT (f32 A only): A is staged as two bf16 terms, hi = bf16(a) and lo = bf16(a - hi), and every weight fragment
+// meets both, so the product carries the activation to ~16 mantissa bits (the latent path's prefill).
+template <bool ABF, bool CBF, bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 As[LBM * LLD];
+    __shared__ __attribute__((aligned(16))) __bf16 Al[SPLIT ? LBM * LLD : 8];
     __shared__ __attribute__((aligned(16))) __bf16 Ws[LBN * LLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -96,6 +99,12 @@ __global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a) {
                 bf16x4 q;
                 q[0] = (__bf16)v.x; q[1] = (__bf16)v.y; q[2] = (__bf16)v.z; q[3] = (__bf16)v.w;
                 *(bf16x4*)&As[row * LLD + p * 4] = q;
+                if constexpr (SPLIT) {
+                    bf16x4 lo;
+                    lo[0] = (__bf16)(v.x - (float)q[0]); lo[1] = (__bf16)(v.y - (float)q[1]);
+                    lo[2] = (__bf16)(v.z - (float)q[2]); lo[3] = (__bf16)(v.w - (float)q[3]);
+                    *(bf16x4*)&Al[row * LLD + p * 4] = lo;
+                }
             }
         }
 #pragma unroll
@@ -121,15 +130,21 @@ __global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a) {
         if (k0 + LBK < K) load_tiles(k0 + LBK);
 #pragma unroll
         for (int ks = 0; ks < LBK / 16; ++ks) {
-            bf16x8 af[2], wf[2];
+            bf16x8 af[2], al[2], wf[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)&As[(wr * 64 + i * 32 + lr) * LLD + ks * 16 + lh * 8];
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *(const bf16x8*)&As[(wr * 64 + i * 32 + lr) * LLD + ks * 16 + lh * 8];
+                if constexpr (SPLIT) al[i] = *(const bf16x8*)&Al[(wr * 64 + i * 32 + lr) * LLD + ks * 16 + lh * 8];
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) wf[j] = *(const bf16x8*)&Ws[(wc * 64 + j * 32 + lr) * LLD + ks * 16 + lh * 8];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (SPLIT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], al[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile
+                }
         }
         __syncthreads();
     }
@@ -191,7 +206,8 @@ __global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a) {
 
 // Whether launch_gemm may hand this problem to the lean kernel.
 bool gemm_lean_eligible(const GemmArgs& a) {
-    if (a.wtype != W_BF16 || a.split_a || a.G || a.act_pre != ACT_NONE) return false;
+    if (a.wtype != W_BF16 || a.G || a.act_pre != ACT_NONE) return false;
+    if (a.split_a && (a.a_bf16 || a.c_bf16)) return false;
     // small problems: the 64 x 64 tiles of the general kernel fill the chip better (bf16 rows exist only here)
     if (!(a.a_bf16 || a.c_bf16) && (a.M < 512 || a.N < 32)) return false;
     if ((a.N & 3) || (a.K & 7) || (a.ldc & 3) || (a.c_bs & 3)) return false;
@@ -207,12 +223,14 @@ bool gemm_lean_eligible(const GemmArgs& a) {
 
 void launch_gemm_lean(const GemmArgs& a, hipStream_t s) {
     dim3 grid((a.M + LBM - 1) / LBM, (a.N + LBN - 1) / LBN), block(256);
-    if (a.a_bf16) {
-        if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_lean_kernel<true, false>), grid, block, 0, s, a);
+    if (a.split_a) {
+        hipLaunchKernelGGL((gemm_lean_kernel<false, false, true>), grid, block, 0, s, a);
+    } else if (a.a_bf16) {
+        if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<true, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_lean_kernel<true, false, false>), grid, block, 0, s, a);
     } else {
-        if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_lean_kernel<false, false>), grid, block, 0, s, a);
+        if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<false, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_lean_kernel<false, false, false>), grid, block, 0, s, a);
     }
 }
 
