@@ -134,6 +134,13 @@ POCKET_TTS_API int ptts_audio_normalize(const float* in, int n, float* out);
  * arithmetic exactly; the model paths call the same kernel. */
 POCKET_TTS_API int ptts_q8_linear(PocketTTSHandle handle, const float* A, int M, int K, const float* W, int N, float* out);
 
+/* The bf16-weight matrix product on its own: out[M][N] = act(A . W^T + bias) * colscale + R (bias, colscale, R may be
+ * NULL; act: 0 none, 1 GELU, 2 SiLU, 3 ELU; W is rounded to bf16).  flags bit 0: carry A as two bf16 terms; bit 1: keep
+ * the A rows in bf16 in device memory; bit 2: keep the C rows in bf16.  For checking the kernels at arbitrary shapes; the
+ * model paths go through the same dispatch. */
+POCKET_TTS_API int ptts_bf16_linear(PocketTTSHandle handle, const float* A, int M, int K, const float* W, int N, const float* bias,
+                                    const float* colscale, const float* R, int act, int flags, float* out);
+
 POCKET_TTS_API int ptts_phase_timing(PocketTTSHandle handle, int enable);
 /* Coalescing of concurrent single-utterance calls (pocket_tts_generate, pocket_tts_generate_ids with n = 1):
  * stats[0] = batches run, stats[1] = utterances served, stats[2] = largest batch. */

@@ -502,6 +502,15 @@ POCKET_TTS_API int ptts_q8_linear(PocketTTSHandle handle, const float* A, int M,
     });
 }
 
+POCKET_TTS_API int ptts_bf16_linear(PocketTTSHandle handle, const float* A, int M, int K, const float* W, int N, const float* bias,
+                                    const float* colscale, const float* R, int act, int flags, float* out) {
+    if (!handle || !A || !W || !out || M <= 0 || N <= 0 || K <= 0) { set_error("Invalid parameters"); return -1; }
+    return guarded("bf16_linear: ", [&] {
+        tts_of(handle)->engine().bf16_linear(A, M, K, W, N, bias, colscale, R, act, flags, out);
+        return 0;
+    });
+}
+
 POCKET_TTS_API int ptts_scheduler_stats(PocketTTSHandle handle, long* stats) {
     if (!handle || !stats) { set_error("Invalid parameters"); return -1; }
     return guarded("scheduler_stats: ", [&] {

@@ -13,14 +13,6 @@ namespace ptts {
 
 namespace {
 
-uint16_t f32_to_bf16(float f) {
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);  // keep NaN a NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return static_cast<uint16_t>(u >> 16);
-}
-
 bool ends_with(const std::string& s, const std::string& suf) {
     return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
 }

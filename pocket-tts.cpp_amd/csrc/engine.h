@@ -3,6 +3,8 @@
 // (:133-239).  All recurrent state (KV caches, convolution histories, positions) lives in HBM for the
 // life of a batch and is never copied to the host.
 #pragma once
+#include <cstring>
+#include <cstdint>
 
 #include <atomic>
 #include <condition_variable>
@@ -19,6 +21,16 @@
 #include "kernels.h"
 
 namespace ptts {
+
+// float32 -> nearest-even bfloat16 bits
+inline uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);  // keep NaN a NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return static_cast<uint16_t>(u >> 16);
+}
+
 
 enum class Precision { FP32, BF16, INT8 };   // INT8: bf16 engine with int8 LM-layer and flow-block matrices
 
@@ -165,6 +177,8 @@ public:
     void op_flow_euler(const float* cond, const float* x0, int B, float* x_out);
     void op_mimi_decode(Batch* b, const float* latents /*[B][n][latent]*/, int n, float* audio /*[B][n*frame]*/);
     void q8_linear(const float* A, int M, int K, const float* W, int N, float* out);   // the int8 product kernel alone
+    void bf16_linear(const float* A, int M, int K, const float* W, int N, const float* bias, const float* colscale, const float* R, int act,
+                     int flags, float* out);   // the bf16 GEMM dispatch alone
 
     // timing hooks for the benchmark: HIP events recorded on the engine stream around named phases
     struct PhaseTimes { double lm_ms = 0, flow_ms = 0, dec_ms = 0, head_ms = 0; long lm_calls = 0, flow_calls = 0, dec_calls = 0, head_calls = 0; };

@@ -586,6 +586,48 @@ void Engine::q8_linear(const float* A, int M, int K, const float* W, int N, floa
     PTTS_HIP(hipStreamSynchronize(stream_));
 }
 
+// The bf16-weight GEMM dispatch on its own (test support): C = act(A . W^T + bias) * colscale + R with the options
+// that choose between the kernels; flags bit 0: two-term A, bit 1: A rows bf16 in memory, bit 2: C rows bf16.
+void Engine::bf16_linear(const float* A, int M, int K, const float* W, int N, const float* bias, const float* colscale, const float* R,
+                         int act, int flags, float* out) {
+    std::lock_guard<std::mutex> guard(mu_);
+    PTTS_HIP(hipSetDevice(opt_.device));
+    const bool abf = flags & 2, cbf = flags & 4;
+    std::vector<uint16_t> wq(static_cast<size_t>(N) * K), aq;
+    for (size_t i = 0; i < wq.size(); ++i) wq[i] = f32_to_bf16(W[i]);
+    DevBuf dA(static_cast<size_t>(M) * K * 4 + 64), dW(wq.size() * 2 + 64), dC(static_cast<size_t>(M) * N * 4 + 64), dB(static_cast<size_t>(N) * 4 + 64),
+        dS(static_cast<size_t>(N) * 4 + 64), dR(static_cast<size_t>(M) * N * 4 + 64);
+    if (abf) {
+        aq.resize(static_cast<size_t>(M) * K);
+        for (size_t i = 0; i < aq.size(); ++i) aq[i] = f32_to_bf16(A[i]);
+        PTTS_HIP(hipMemcpyAsync(dA.p, aq.data(), aq.size() * 2, hipMemcpyHostToDevice, stream_));
+    } else {
+        PTTS_HIP(hipMemcpyAsync(dA.p, A, static_cast<size_t>(M) * K * 4, hipMemcpyHostToDevice, stream_));
+    }
+    PTTS_HIP(hipMemcpyAsync(dW.p, wq.data(), wq.size() * 2, hipMemcpyHostToDevice, stream_));
+    if (bias) PTTS_HIP(hipMemcpyAsync(dB.p, bias, static_cast<size_t>(N) * 4, hipMemcpyHostToDevice, stream_));
+    if (colscale) PTTS_HIP(hipMemcpyAsync(dS.p, colscale, static_cast<size_t>(N) * 4, hipMemcpyHostToDevice, stream_));
+    if (R) PTTS_HIP(hipMemcpyAsync(dR.p, R, static_cast<size_t>(M) * N * 4, hipMemcpyHostToDevice, stream_));
+    GemmArgs g;
+    g.A = dA.f(); g.lda = K; g.W = dW.p; g.wtype = W_BF16; g.M = M; g.N = N; g.K = K; g.C = dC.f(); g.ldc = N;
+    g.bias = bias ? dB.f() : nullptr; g.colscale = colscale ? dS.f() : nullptr;
+    if (R) { g.R = dR.f(); g.ldr = N; }
+    g.c_act = act; g.split_a = flags & 1; g.a_bf16 = abf; g.c_bf16 = cbf;
+    launch_gemm(g, stream_);
+    if (cbf) {
+        std::vector<uint16_t> cq(static_cast<size_t>(M) * N);
+        PTTS_HIP(hipMemcpyAsync(cq.data(), dC.p, cq.size() * 2, hipMemcpyDeviceToHost, stream_));
+        PTTS_HIP(hipStreamSynchronize(stream_));
+        for (size_t i = 0; i < cq.size(); ++i) {
+            const uint32_t u = static_cast<uint32_t>(cq[i]) << 16;
+            std::memcpy(out + i, &u, 4);
+        }
+    } else {
+        PTTS_HIP(hipMemcpyAsync(out, dC.p, static_cast<size_t>(M) * N * 4, hipMemcpyDeviceToHost, stream_));
+        PTTS_HIP(hipStreamSynchronize(stream_));
+    }
+}
+
 void Engine::op_mimi_decode(Batch* b, const float* latents, int n, float* audio) {
     std::lock_guard<std::mutex> guard(mu_);
     PTTS_HIP(hipSetDevice(opt_.device));

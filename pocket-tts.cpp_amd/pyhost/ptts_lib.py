@@ -51,7 +51,7 @@ EXT_SYMBOLS = [
     "pocket_tts_stage_ids", "pocket_tts_run_staged", "pocket_tts_fetch_staged",
     "pocket_tts_tokenize", "ptts_text_conditioner", "ptts_state_new", "ptts_state_free", "ptts_state_reset",
     "ptts_lm_prefill", "ptts_lm_step", "ptts_flow_euler", "ptts_mimi_decode", "ptts_mimi_encode",
-    "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_q8_linear",
+    "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_q8_linear", "ptts_bf16_linear",
     "ptts_tokenizer_new", "ptts_tokenizer_free", "ptts_tokenizer_vocab", "ptts_tokenizer_encode",
     "ptts_audio_load_wav", "ptts_audio_save_wav", "ptts_audio_resample", "ptts_audio_normalize",
     "ptts_onnx_open", "ptts_onnx_close", "ptts_onnx_tensor_count", "ptts_onnx_tensor_info", "ptts_onnx_find",
@@ -114,6 +114,8 @@ def load() -> C.CDLL:
     L.ptts_phase_times.restype = ci; L.ptts_phase_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.ptts_scheduler_stats.restype = ci; L.ptts_scheduler_stats.argtypes = [vp, C.POINTER(C.c_long)]
     L.ptts_q8_linear.restype = ci; L.ptts_q8_linear.argtypes = [vp, f32p, ci, ci, f32p, ci, f32p]
+    L.ptts_bf16_linear.restype = ci
+    L.ptts_bf16_linear.argtypes = [vp, f32p, ci, ci, f32p, ci, vp, vp, vp, ci, ci, f32p]
     L.ptts_weight_bytes.restype = ci; L.ptts_weight_bytes.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.ptts_tokenizer_new.restype = vp; L.ptts_tokenizer_new.argtypes = [cp]
     L.ptts_tokenizer_free.restype = None; L.ptts_tokenizer_free.argtypes = [vp]
@@ -425,6 +427,17 @@ class Engine:
         W = np.ascontiguousarray(W, np.float32)
         out = np.empty((A.shape[0], W.shape[0]), np.float32)
         _check(self.L.ptts_q8_linear(self.h, A, A.shape[0], A.shape[1], W, W.shape[0], out), "q8_linear")
+        return out
+
+    def bf16_linear(self, A, W, bias=None, colscale=None, R=None, act=0, split_a=False, a_bf16=False, c_bf16=False) -> np.ndarray:
+        """act(A . W^T + bias) * colscale + R through the engine's bf16-weight GEMM dispatch (W rounded to bf16)."""
+        A = np.ascontiguousarray(A, np.float32)
+        W = np.ascontiguousarray(W, np.float32)
+        keep = [None if v is None else np.ascontiguousarray(v, np.float32) for v in (bias, colscale, R)]
+        ptrs = [None if v is None else v.ctypes.data_as(C.c_void_p) for v in keep]
+        out = np.empty((A.shape[0], W.shape[0]), np.float32)
+        flags = (1 if split_a else 0) | (2 if a_bf16 else 0) | (4 if c_bf16 else 0)
+        _check(self.L.ptts_bf16_linear(self.h, A, A.shape[0], A.shape[1], W, W.shape[0], ptrs[0], ptrs[1], ptrs[2], act, flags, out), "bf16_linear")
         return out
 
     def scheduler_stats(self):
