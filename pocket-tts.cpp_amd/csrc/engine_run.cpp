@@ -262,7 +262,10 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
         std::lock_guard<std::mutex> g(ev_mu_);
         times_.lm_ms += lm; times_.lm_calls++;
         times_.flow_ms += fl; times_.flow_calls++;
-        times_.head_ms += hd; times_.head_calls += opt_.lsd_steps * (spec().flow_blocks + 1);
+        FlowHeadArgs fa;
+        fa.C = spec().flow_dim; fa.B = b.B; fa.steps = opt_.lsd_steps; fa.blocks = spec().flow_blocks;
+        fa.wtype = model_->flow_wtype; fa.block_wtype = model_->flow_block_wtype;
+        times_.head_ms += hd; times_.head_calls += flow_head_launch_count(fa);
     };
 
     size_t n_finished = 0;

@@ -261,11 +261,20 @@ struct FlowBlockArgs {
     int B = 0, mod_width = 0, rpg = 16;   // rpg: utterance rows per workgroup row group (<= 16, the MFMA tile height)
     long long* cycles = nullptr;          // optional [8]: s_memtime of workgroup (0,0) wave 0 at the phase boundaries (tuning aid)
     float eps = 1e-6f;
+    // first block of Euler steps 1..: the tail of the previous step (last residual update, final adaLN, output projection,
+    // x += dt * v) is done here by every workgroup of the row group instead of in a launch of its own (FIN kernels only)
+    const float* fin_h = nullptr; const float* fin_part = nullptr;    // residual stream / partials of the previous step's last block
+    const float* fin_mods = nullptr; const float* fin_b2 = nullptr;   // the previous step's adaLN vectors; fc2 bias of its last block
+    const float* fin_x = nullptr; long long fin_x_stride = 0;         // x before the previous step
+    const int* fin_x_step = nullptr; long long fin_x_step_stride = 0;
+    float* fin_x_out = nullptr;                                       // x after it, [B][L] (written by workgroup 0 of the row group)
+    const void* w_out = nullptr; const float* b_out = nullptr;
+    int blocks = 0; float dt = 0.f;
 };
 
 // C = flow_dim, G = column/K split, L = latent_dim; PF: request every weight fragment of the launch up front
 // (needs (C/16/G/8 * C/kstep + C/16/8 * C/kstep/G) * 4 VGPRs, so only for bf16 at C <= 512).
-template <typename WT, int C, int G, int L, bool PF, int RPW>
+template <typename WT, int C, int G, int L, bool PF, int RPW, bool FIN = false>
 __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using T = FlowTraits<WT>;
@@ -337,11 +346,61 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
     // ---- residual stream rows of this wave
     float4 h[RPW][RM::NP];
     if (a.first) {
-        const float* xin = a.x_in + (a.x_step ? (long long)(*a.x_step) * a.x_step_stride : 0);
-        for (int i = tid; i < 16 * L; i += kFlowThreads) {
-            const int r = i / L, c = i % L;
-            const float v = r < nrows ? xin[(long long)(row0 + r) * a.x_stride + c] : 0.f;
-            put_act<WT>(X0, X1, r * ldx + c, v);
+        bool staged = false;
+        if constexpr (FIN) {
+            if (a.fin_part) {
+                // ---- tail of the previous Euler step, redundantly in every workgroup of the row group
+                constexpr int NTL = L / 16, KPARTS = kFlowWaves / NTL, KSP = KS / KPARTS;
+                static_assert(kFlowWaves % NTL == 0 && KS % KPARTS == 0, "flow head: output projection does not tile");
+                const float* mfin = a.fin_mods + a.blocks * 3 * C;
+                ModRegs<C, RPW> mf;
+                ResRegs<C, G, RPW> rf;
+                if (live) {
+                    load_mod<C, false, RPW>(mf, nullptr, nullptr, mfin, mfin + C, a.mod_width, row0, nrows, wave, lane);
+                    residual_load<C, G, RPW>(rf, a.fin_h, a.fin_part, (long long)a.B * C, a.fin_mods + (a.blocks - 1) * 3 * C + 2 * C, a.mod_width,
+                                             a.fin_b2, row0, nrows, wave, lane);
+                }
+                const int to = wave % NTL, kpo = wave / NTL;
+                uint4 wo[KSP];
+#pragma unroll
+                for (int ks = 0; ks < KSP; ++ks) wo[ks] = ((const uint4*)a.w_out)[((long long)to * KS + kpo * KSP + ks) * 64 + lane];
+                if (live) {
+                    float4 hf[RPW][RM::NP];
+                    residual_finish<C, G, RPW>(hf, rf);
+                    norm_apply<WT, C, RPW>(hf, mf, A0, A1, lda, a.eps, wave, lane);
+                }
+                __syncthreads();
+                f32x4 acco = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KSP; ++ks) mma_frag<WT>(A0, A1, lda, (kpo * KSP + ks) * KSTEP, wo[ks], acco, lane);
+                float* redo = hbuf;                            // [waves][256]; hbuf is not in use yet
+                *(f32x4*)(redo + wave * 256 + lane * 4) = acco;
+                __syncthreads();
+                const float* xp = a.fin_x + (a.fin_x_step ? (long long)(*a.fin_x_step) * a.fin_x_step_stride : 0);
+                for (int i = tid; i < 16 * L; i += kFlowThreads) {
+                    const int r = i / L, c = i % L;
+                    float v = 0.f;
+                    if (r < nrows) {
+                        const int tt = c / 16, ln = (r / 4) * 16 + (c % 16), ri = r % 4;   // accumulator of tile tt: lane ln, element ri
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int k = 0; k < KPARTS; ++k) sacc += redo[(k * NTL + tt) * 256 + ln * 4 + ri];
+                        const long long row = row0 + r;
+                        v = xp[row * a.fin_x_stride + c] + (sacc + a.b_out[c]) * a.dt;
+                        if (g == 0) a.fin_x_out[row * L + c] = v;
+                    }
+                    put_act<WT>(X0, X1, r * ldx + c, v);
+                }
+                staged = true;
+            }
+        }
+        if (!staged) {
+            const float* xin = a.x_in + (a.x_step ? (long long)(*a.x_step) * a.x_step_stride : 0);
+            for (int i = tid; i < 16 * L; i += kFlowThreads) {
+                const int r = i / L, c = i % L;
+                const float v = r < nrows ? xin[(long long)(row0 + r) * a.x_stride + c] : 0.f;
+                put_act<WT>(X0, X1, r * ldx + c, v);
+            }
         }
         __syncthreads();
         uint4 wi[T2][KSL];
@@ -791,7 +850,7 @@ static void flow_head_shape(int C, int B, bool bf, int& G, int& rpg) {
 
 size_t flow_head_workspace_bytes(int B, int C, int wtype) {
     (void)wtype;
-    return ((size_t)2 * B * C + (size_t)2 * kMaxFlowSplit * B * C) * sizeof(float);
+    return ((size_t)2 * B * C + (size_t)2 * kMaxFlowSplit * B * C + (size_t)2 * B * 32) * sizeof(float);   // h x2, partials x2, x x2
 }
 
 // hipFuncSetAttribute is per device and per kernel; remember where it has been applied.
@@ -806,7 +865,8 @@ static void set_lds_limit(const void* kernel, size_t smem) {
         (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-template <typename WT, int C, bool PF, int G = 4, int RPW = 2>
+// FUSE: the tail of Euler step j-1 runs inside the first block launch of step j (one launch less per step)
+template <typename WT, int C, bool PF, int G = 4, int RPW = 2, bool FUSE = false>
 static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
     constexpr int L = 32;
     using T = FlowTraits<WT>;
@@ -814,9 +874,11 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
     const size_t smem_block = (size_t)16 * C * 4 + (size_t)T::planes * 16 * ((C + T::pad) + (C / G + T::pad) + (L + T::pad)) * sizeof(WT);
     const size_t smem_final = (size_t)T::planes * 16 * (C + T::pad) * sizeof(WT) + (size_t)kFlowWaves * 256 * 4;
     auto kb = flow_block_kernel<WT, C, G, L, PF, RPW>;
+    auto kbf = flow_block_kernel<WT, C, G, L, PF, RPW, FUSE>;
     auto kf = flow_final_kernel<WT, C, G, L, RPW>;
     if (rpg > RPW * kFlowWaves) throw std::runtime_error("flow head: row group larger than the waves can cover");
     set_lds_limit((const void*)kb, smem_block);
+    set_lds_limit((const void*)kbf, smem_block);
     set_lds_limit((const void*)kf, smem_final);
     const bool q8 = a.block_wtype == W_I8;
     size_t smem_q8 = 0;
@@ -835,9 +897,12 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
     const FlowHostTabs& tabs = *a.host_tabs;
     int cur = 0;
     if (a.probe_a) (void)hipEventRecord(a.probe_a, s);   // the probe brackets the whole chain: steps * (blocks + 1) launches
+    const bool fuse = FUSE && !q8;
+    float* xb[2] = {pb[1] + (size_t)kMaxFlowSplit * B * C, pb[1] + (size_t)kMaxFlowSplit * B * C + (size_t)B * L};   // x after odd / even steps
     for (int j = 0; j < a.steps; ++j) {
         const float* mods_j = a.mods + (size_t)j * B * a.mod_width;
-        const float* x_in = j == 0 ? a.x0 : a.x_out;
+        // x before step j: the caller's start point, then (unfused) the output buffer, (fused) the ping-pong pair
+        const float* x_in = j == 0 ? a.x0 : (fuse ? xb[j & 1] : a.x_out);
         const long long x_stride = j == 0 ? a.x0_stride : (long long)L;
         for (int blk = 0; blk < a.blocks; ++blk) {
             FlowBlockArgs fb;
@@ -851,10 +916,21 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
             if (q8) { fb.s1 = tabs.s_fc1[blk]; fb.s2 = tabs.s_fc2[blk]; }
             fb.B = B; fb.mod_width = a.mod_width; fb.eps = a.eps; fb.rpg = rpg;
             if (a.cycle_probe && j == 1 && blk == 2) fb.cycles = a.cycle_probe;
+            const bool fin = fuse && blk == 0 && j > 0;
+            if (fin) {   // x_j = x_{j-1} + dt * v_{j-1} from the previous step's last block, then this step's first block
+                fb.fin_h = hb[cur ^ 1]; fb.fin_part = pb[cur ^ 1]; fb.fin_mods = a.mods + (size_t)(j - 1) * B * a.mod_width;
+                fb.fin_b2 = tabs.b_fc2[a.blocks - 1];
+                fb.fin_x = j == 1 ? a.x0 : xb[(j - 1) & 1]; fb.fin_x_stride = j == 1 ? a.x0_stride : (long long)L;
+                if (j == 1) { fb.fin_x_step = a.x0_step; fb.fin_x_step_stride = a.x0_step_stride; }
+                fb.fin_x_out = xb[j & 1];
+                fb.w_out = a.w_out; fb.b_out = a.b_out; fb.blocks = a.blocks; fb.dt = 1.0f / (float)a.steps;
+            }
             if (q8) hipLaunchKernelGGL(kq, dim3(G, RG), dim3(kFlowThreads), smem_q8, s, fb);
+            else if (fin) hipLaunchKernelGGL(kbf, dim3(G, RG), dim3(kFlowThreads), smem_block, s, fb);
             else hipLaunchKernelGGL(kb, dim3(G, RG), dim3(kFlowThreads), smem_block, s, fb);
             cur ^= 1;
         }
+        if (fuse && j + 1 < a.steps) continue;   // this step's tail runs in the next step's first launch
         FlowFinalArgs ff;
         ff.h_prev = hb[cur ^ 1]; ff.part_prev = pb[cur ^ 1]; ff.mods = mods_j; ff.prev_b2 = tabs.b_fc2[a.blocks - 1];
         ff.x_in = x_in; ff.x_stride = x_stride; ff.x_out = a.x_out;
@@ -879,12 +955,25 @@ void flow_head_prepare(int C, int wtype) {
         case 128: bf ? prepare_chain<__bf16, 128, true>() : prepare_chain<float, 128, false>(); break;
         case 256: bf ? prepare_chain<__bf16, 256, true>() : prepare_chain<float, 256, false>(); break;
         case 512:
-            if (bf) { prepare_chain<__bf16, 512, true>(); prepare_chain<__bf16, 512, true, 4, 1>(); prepare_chain<__bf16, 512, true, 8, 1>(); }
+            if (bf) {
+                prepare_chain<__bf16, 512, true>(); prepare_chain<__bf16, 512, true, 4, 1>(); prepare_chain<__bf16, 512, true, 8, 1>();
+                set_lds_limit((const void*)flow_block_kernel<__bf16, 512, 4, 32, true, 1, true>, 128 * 1024);
+            }
             else prepare_chain<float, 512, false>();
             break;
         case 1024: bf ? prepare_chain<__bf16, 1024, false>() : prepare_chain<float, 1024, false>(); break;
         default: throw std::runtime_error("flow head: flow_dim must be 128, 256, 512 or 1024");
     }
+}
+
+// Launches one call of launch_flow_head makes: steps * blocks block launches plus one tail launch per step, or one
+// tail launch in all where the tails ride in the next step's first block launch.
+int flow_head_launch_count(const FlowHeadArgs& a) {
+    const bool bf = a.wtype == W_BF16, q8 = a.block_wtype == W_I8;
+    int G = 4, rpg = 16;
+    flow_head_shape(a.C, a.B, bf, G, rpg);
+    const bool fused = a.C == 512 && bf && !q8 && G != 8 && rpg <= 8 && !std::getenv("FLOW_HEAD_NO_FUSE");
+    return a.steps * a.blocks + (fused ? 1 : a.steps);
 }
 
 void launch_flow_head(const FlowHeadArgs& a, hipStream_t s) {
@@ -901,6 +990,7 @@ void launch_flow_head(const FlowHeadArgs& a, hipStream_t s) {
         case 256: bf ? run_chain<__bf16, 256, true>(a, s, rpg) : run_chain<float, 256, false>(a, s, rpg); break;
         case 512:
             if (bf && !q8 && G == 8 && rpg <= 8) run_chain<__bf16, 512, true, 8, 1>(a, s, rpg);
+            else if (bf && rpg <= 8 && !std::getenv("FLOW_HEAD_NO_FUSE")) run_chain<__bf16, 512, true, 4, 1, true>(a, s, rpg);
             else if (bf && rpg <= 8) run_chain<__bf16, 512, true, 4, 1>(a, s, rpg);
             else if (bf) run_chain<__bf16, 512, true>(a, s, rpg);
             else run_chain<float, 512, false>(a, s, rpg);

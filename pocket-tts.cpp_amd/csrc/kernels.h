@@ -146,6 +146,7 @@ struct FlowHeadArgs {
     long long* cycle_probe = nullptr;   // optional device [8]: cycle counter at the phase boundaries of one mid-chain block launch
 };
 void launch_flow_head(const FlowHeadArgs& a, hipStream_t s);
+int flow_head_launch_count(const FlowHeadArgs& a);   // kernel launches one call makes (only C, B, steps, blocks, wtype, block_wtype are read)
 size_t flow_head_workspace_bytes(int B, int C, int wtype);
 void flow_head_prepare(int C, int wtype);   // once per device, outside stream capture
 // Host-side reorder of a flow-head weight W[N][K] into the fragment-major layout the kernel streams.
