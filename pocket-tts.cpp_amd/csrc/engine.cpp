@@ -775,20 +775,24 @@ static int pick_splits(int K, int kstep) {
 // One new row per utterance.  Per layer: QKV product -> rotate/append/attend -> output product as K-slices ->
 // add & norm -> FFN-1 product with GELU -> FFN-2 product as K-slices -> add & norm (which also produces the
 // next layer's normalised input, or after the last layer the conditioning vector and the EOS logit).
-void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev) {
+void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev, bool prepped) {
     const Spec& s = spec();
     const int B = b.B, D = s.d_model, F = s.lm_ffn;
     const int wt = model_->lm_wtype, kstep = wt == W_I8 ? 64 : wt == W_BF16 ? 32 : 16;
-    launch_prep_latent(seq_dev, b.seq_in.f(), B, s.latent, 0, hd_.bos, nullptr, b.st);
+    const float* seq_rows = seq_dev;
+    if (!prepped) {
+        launch_prep_latent(seq_dev, b.seq_in.f(), B, s.latent, 0, hd_.bos, nullptr, b.st);
+        seq_rows = b.seq_in.f();
+    }
     if (model_->lm_in_packed && s.latent % 4 == 0) {
         SkinnyArgs g;
-        g.A = b.seq_in.f(); g.lda = s.latent; g.Wp = model_->lm_in_packed; g.wtype = model_->flow_wtype; g.M = B; g.N = D; g.K = s.latent;
+        g.A = seq_rows; g.lda = s.latent; g.Wp = model_->lm_in_packed; g.wtype = model_->flow_wtype; g.M = B; g.N = D; g.K = s.latent;
         g.C = b.x.f(); g.ldc = D;
         launch_skinny_gemm(g, b.st);
     } else {
         const DevWeight& win = hd_.lm_in;
         GemmArgs g;
-        g.A = b.seq_in.f(); g.lda = s.latent; g.W = win.p; g.wtype = win.wtype; g.C = b.x.f(); g.ldc = D;
+        g.A = seq_rows; g.lda = s.latent; g.W = win.p; g.wtype = win.wtype; g.C = b.x.f(); g.ldc = D;
         g.M = B; g.N = D; g.K = s.latent; g.split_a = 1;
         launch_gemm(g, b.st);
     }
@@ -854,7 +858,7 @@ void Engine::lm_bookkeeping(Batch& b) {
 
 // lsd_steps Euler iterations for B rows: 3 small launches for the adaLN vectors, then the head's per-block chain.
 void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B,
-                      const int* x0_step, long long x0_step_stride, hipEvent_t probe_a, hipEvent_t probe_b) {
+                      const int* x0_step, long long x0_step_stride, hipEvent_t probe_a, hipEvent_t probe_b, bool frame_mode) {
     const Spec& s = spec();
     const int C = s.flow_dim, N = opt_.lsd_steps;
     // conditioning embedding as K-slice slabs (skinny product), summed inside the next kernel
@@ -864,7 +868,9 @@ void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long
     g.A = cond_dev; g.lda = s.d_model; g.Wp = model_->flow_cond_packed; g.wtype = wt; g.M = B; g.N = C; g.K = s.d_model;
     g.splits = cs; g.P = b.cemb.f();
     launch_skinny_gemm(g, b.st);
-    launch_flow_mod_input(flow_te_.f(), b.cemb.f(), cs, hd_.flow_cond_b, b.ymod.f(), N, B, C, b.st);
+    FramePublish pub;
+    if (frame_mode) { pub.eos = b.eos.f(); pub.step = b.step_dev.as<int>(); pub.h_eos_all = b.h_eos_all; pub.h_flag = b.h_flag; }
+    launch_flow_mod_input(flow_te_.f(), b.cemb.f(), cs, hd_.flow_cond_b, b.ymod.f(), N, B, C, b.st, frame_mode ? &pub : nullptr);
     if (model_->ada_packed) {
         SkinnyArgs m;
         m.A = b.ymod.f(); m.lda = C; m.Wp = model_->ada_packed; m.wtype = wt; m.M = N * B; m.N = model_->mod_width; m.K = C;
@@ -884,6 +890,10 @@ void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long
     fa.host_tabs = &model_->flow_tabs; fa.workspace = b.flow_ws.f(); fa.wtype = model_->flow_wtype; fa.eps = s.flow_eps;
     fa.block_wtype = model_->flow_block_wtype;
     fa.x0_step = x0_step; fa.x0_step_stride = x0_step_stride; fa.probe_a = probe_a; fa.probe_b = probe_b;
+    if (frame_mode) {   // the counter was advanced when the EOS logits were published: the frame index is *step - 1
+        fa.x0_step = b.step_dev.as<int>(); fa.x0_step_bias = -1;
+        fa.latents = b.latents.f(); fa.max_frames = opt_.max_frames;
+    }
     launch_flow_head(fa, b.st);
 }
 

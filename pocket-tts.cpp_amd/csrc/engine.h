@@ -201,9 +201,11 @@ private:
     void lm_bookkeeping(Batch& b);
     void lm_rows_q8(Batch& b, int slot0, int nb, int rpb, float* X);
     void lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* adv_dev = nullptr, const int* adv_host = nullptr);
-    void lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev);
+    // prepped: seq_dev already holds the BOS embedding where the reference passes NaN (no preparation launch)
+    void lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev, bool prepped = false);
     void flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B,
-                  const int* x0_step = nullptr, long long x0_step_stride = 0, hipEvent_t probe_a = nullptr, hipEvent_t probe_b = nullptr);
+                  const int* x0_step = nullptr, long long x0_step_stride = 0, hipEvent_t probe_a = nullptr, hipEvent_t probe_b = nullptr,
+                  bool frame_mode = false);   // frame_mode: EOS publication, frame counter and latent filing ride in the phase's launches
     void mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs, hipStream_t st);
     void prefill_utterance(Batch& b, int slot, const Utterance& u);
     void fill_noise(std::vector<std::mt19937>& rngs, const std::vector<Utterance>& utts, int step, float* host_x0);

@@ -146,18 +146,17 @@ void Engine::frame_body(Batch& b, int parity) {
     hipStream_t st = b.st;
     hipEvent_t* ev = timing_ ? b.tev[parity] : nullptr;
     if (ev) PTTS_HIP(hipEventRecord(ev[0], st));
-    lm_step_dev(b, b.xcur.f(), b.cond.f(), b.eos.f());                                      // :591
-    if (ev) PTTS_HIP(hipEventRecord(ev[1], st));
-    launch_publish_eos(b.eos.f(), b.B, b.step_dev.as<int>(), b.h_eos_all, b.h_flag, st);
-    if (ev) PTTS_HIP(hipEventRecord(ev[2], st));
-    flow_dev(b, b.cond.f(), b.x0_src, b.x0_stride, b.xcur.f(), b.B, b.step_dev.as<int>(), b.x0_step_stride,  // :606-622
-             ev ? ev[3] : nullptr, ev ? ev[4] : nullptr);
+    lm_step_dev(b, b.xcur.f(), b.cond.f(), b.eos.f(), true);                                // :591
+    if (ev) { PTTS_HIP(hipEventRecord(ev[1], st)); PTTS_HIP(hipEventRecord(ev[2], st)); }
+    // flow phase (:606-622); its second launch also publishes the EOS logits and advances the frame counter, its last
+    // launch files the new latent under the frame index
+    flow_dev(b, b.cond.f(), b.x0_src, b.x0_stride, b.xcur.f(), b.B, b.step_dev.as<int>(), b.x0_step_stride, ev ? ev[3] : nullptr,
+             ev ? ev[4] : nullptr, true);
     if (ev) {
         PTTS_HIP(hipEventRecord(ev[5], st));
         PTTS_HIP(hipEventRecord(ev[6], st));   // nothing between these two: what a bracketing pair costs by itself
         PTTS_HIP(hipEventRecord(ev[7], st));
     }
-    launch_store_latent(b.xcur.f(), b.latents.f(), b.B, spec().latent, opt_.max_frames, b.step_dev.as<int>(), st);
 }
 
 // (Re)captures the frame graphs of a batch when its start-point source or the timing mode changed.
@@ -223,9 +222,11 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
         launch_assemble_prefill(b.voice_stage.f(), static_cast<long long>(b.st_vmax) * D, b.ids_stage.as<long long>(), opt_.max_text_tokens,
                                 b.st_nv.as<int>(), b.st_nt.as<int>(), hd_.text_embed, s.vocab + 1, D, rpb, B, b.x.f(), st);
         lm_rows(b, 0, B, rpb, b.x.f(), b.st_len.as<int>(), r.len.data());
-        // BOS marker: NaN latent (:579)
+        // BOS marker: NaN latent (:579), replaced here by the BOS embedding it stands for so that the frame body
+        // needs no preparation launch
         for (int i = 0; i < B * L; ++i) b.h_x0[i] = std::numeric_limits<float>::quiet_NaN();
-        PTTS_HIP(hipMemcpyAsync(b.xcur.p, b.h_x0, static_cast<size_t>(B) * L * 4, hipMemcpyHostToDevice, st));
+        PTTS_HIP(hipMemcpyAsync(b.seq_in.p, b.h_x0, static_cast<size_t>(B) * L * 4, hipMemcpyHostToDevice, st));
+        launch_prep_latent(b.seq_in.f(), b.xcur.f(), B, L, 0, hd_.bos, nullptr, st);
         b.x0_src = b.st_has_noise ? b.noise_all.f() : b.x0.f();
         b.x0_stride = b.st_has_noise ? static_cast<long long>(opt_.max_frames) * L : L;
         b.x0_step_stride = b.st_has_noise ? L : 0;

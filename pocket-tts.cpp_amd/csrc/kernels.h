@@ -132,6 +132,8 @@ struct FlowHeadArgs {
     const float* x0 = nullptr;    // start points, row b at x0 + b * x0_stride (+ *x0_step * x0_step_stride if x0_step is set)
     long long x0_stride = 0;
     const int* x0_step = nullptr; long long x0_step_stride = 0;
+    int x0_step_bias = 0;         // added to *x0_step wherever it is used
+    float* latents = nullptr; int max_frames = 0;   // optional (needs x0_step): x_out is also filed as latents[b][*x0_step + bias][:]
     hipEvent_t probe_a = nullptr, probe_b = nullptr;   // optional: recorded around the whole chain of steps * (blocks + 1) launches
     float* x_out = nullptr;       // [B][L]; also carries x between Euler steps (must not alias x0)
     const float* mods = nullptr;  // [steps][B][mod_width]
@@ -202,11 +204,12 @@ struct AttnDecodeArgs {
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
 
 // Y[j][b][:] = silu(te[j][:] + sum_s cemb[s][b][:] + bias)   (input rows of the stacked adaLN GEMM)
-void launch_flow_mod_input(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C, hipStream_t s);
-
-// Frame bookkeeping on the device (see ops.hip): EOS logits of step *step -> h_eos_all[*step][B] in mapped host
-// memory, then h_flag = *step + 1;  latents[b][*step][:] = xcur[b][:], then *step += 1.
-void launch_publish_eos(const float* eos, int B, const int* step, float* h_eos_all, int* h_flag, hipStream_t s);
-void launch_store_latent(const float* xcur, float* latents, int B, int L, int max_frames, int* step, hipStream_t s);
+// Optional frame bookkeeping riding in the same launch (block 0): the EOS logits of frame *step go to h_eos_all[*step][B]
+// in mapped host memory, then h_flag = *step + 1 and *step += 1 (so later kernels of the frame see the index plus one).
+struct FramePublish {
+    const float* eos = nullptr; int* step = nullptr; float* h_eos_all = nullptr; int* h_flag = nullptr;
+};
+void launch_flow_mod_input(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C, hipStream_t s,
+                           const FramePublish* pub = nullptr);
 
 }  // namespace ptts

@@ -411,51 +411,39 @@ void launch_shift_history(float* buf, long long bs, int T, int H, int C, int B, 
 
 // cemb is given as `splits` K-slice slabs [splits][B][C] of the conditioning product plus its bias; the slabs are
 // added in slice order.
-__global__ void flow_mod_input_kernel(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C) {
+// A frame of the autoregressive loop is replayed as one hipGraph, so nothing in it may depend on a host-side frame
+// index: the index lives in device memory.  Block 0 of this launch also hands the EOS logits of the current frame to
+// the host through mapped pinned memory, raises the host-visible flag and advances the index.
+__global__ void flow_mod_input_kernel(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C,
+                                      FramePublish pub) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)steps * B * C) return;
-    int c = (int)(i % C);
-    long long jb = i / C;
-    int b = (int)(jb % B), j = (int)(jb / B);
-    float e = cemb[(long long)b * C + c];
-    for (int s = 1; s < splits; ++s) e += cemb[((long long)s * B + b) * C + c];
-    if (bias) e += bias[c];
-    float v = te[(long long)j * C + c] + e;
-    Y[i] = v / (1.0f + expf(-v));
+    if (i < (long long)steps * B * C) {
+        int c = (int)(i % C);
+        long long jb = i / C;
+        int b = (int)(jb % B), j = (int)(jb / B);
+        float e = cemb[(long long)b * C + c];
+        for (int s = 1; s < splits; ++s) e += cemb[((long long)s * B + b) * C + c];
+        if (bias) e += bias[c];
+        float v = te[(long long)j * C + c] + e;
+        Y[i] = v / (1.0f + expf(-v));
+    }
+    if (pub.step && blockIdx.x == 0) {   // frame bookkeeping: see FramePublish
+        const int st = *pub.step;
+        for (int b = threadIdx.x; b < B; b += blockDim.x) pub.h_eos_all[(long long)st * B + b] = pub.eos[b];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(pub.h_flag, st + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            *pub.step = st + 1;
+        }
+    }
 }
-void launch_flow_mod_input(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C, hipStream_t s) {
+void launch_flow_mod_input(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C, hipStream_t s,
+                           const FramePublish* pub) {
     long long n = (long long)steps * B * C;
     if (n <= 0) return;
-    hipLaunchKernelGGL(flow_mod_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, te, cemb, splits, bias, Y, steps, B, C);
-}
-
-// ------------------------------------------------------------------ per-frame bookkeeping kept on the device
-// A frame of the autoregressive loop is replayed as one hipGraph, so nothing in it may depend on a host-side
-// frame index: the index lives in *step.  publish_eos hands the EOS logits of the current step to the host
-// through mapped pinned memory and then raises the host-visible step flag; store_latent files the new latent
-// under the current index and advances it.
-__global__ void publish_eos_kernel(const float* eos, int B, const int* step, float* h_eos_all, int* h_flag) {
-    const int st = *step;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) h_eos_all[(long long)st * B + b] = eos[b];
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(h_flag, st + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-void launch_publish_eos(const float* eos, int B, const int* step, float* h_eos_all, int* h_flag, hipStream_t s) {
-    hipLaunchKernelGGL(publish_eos_kernel, dim3(1), dim3(256), 0, s, eos, B, step, h_eos_all, h_flag);
-}
-
-__global__ void store_latent_kernel(const float* xcur, float* latents, int B, int L, int max_frames, int* step) {
-    const int st = *step;
-    for (int i = threadIdx.x; i < B * L; i += blockDim.x) {
-        const int b = i / L, l = i % L;
-        latents[((long long)b * max_frames + st) * L + l] = xcur[i];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) *step = st + 1;
-}
-void launch_store_latent(const float* xcur, float* latents, int B, int L, int max_frames, int* step, hipStream_t s) {
-    hipLaunchKernelGGL(store_latent_kernel, dim3(1), dim3(256), 0, s, xcur, latents, B, L, max_frames, step);
+    hipLaunchKernelGGL(flow_mod_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, te, cemb, splits, bias, Y, steps, B, C,
+                       pub ? *pub : FramePublish());
 }
 
 }  // namespace ptts
