@@ -376,26 +376,32 @@ __device__ __forceinline__ float block_sum4(float v, float* red, int tid) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+template <int MAXS>
 __global__ __launch_bounds__(256) void add_norm_kernel(AddNormArgs a) {
-    constexpr int MAXS = 16;
     __shared__ float red[4];
     const int tid = threadIdx.x, m = blockIdx.x;
     const int c = 4 * tid;
     const bool on = c < a.D;
+    const int cc = on ? c : 0;                       // lanes past the row read column 0 and store nothing
     float* __restrict__ xr = a.X + (long long)m * a.ldx;
     const float* __restrict__ P = a.P;
-    float4 v = on ? *(const float4*)(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (P) {
-        float4 part[MAXS];
+    // every operand of the launch is requested here, before anything is waited for
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = *(const float4*)(xr + cc);
+    float4 part[MAXS];
 #pragma unroll
-        for (int k = 0; k < MAXS; ++k)
-            part[k] = (on && k < a.splits) ? *(const float4*)(P + ((long long)k * a.M + m) * a.D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < MAXS; ++k) part[k] = (P && k < a.splits) ? *(const float4*)(P + ((long long)k * a.M + m) * a.D + cc) : zero;
+    const float4 pb4 = (P && a.pbias) ? *(const float4*)(a.pbias + cc) : zero;
+    const float4 s4 = (P && a.colscale) ? *(const float4*)(a.colscale + cc) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 g4 = a.g ? *(const float4*)(a.g + cc) : zero, b4 = a.g ? *(const float4*)(a.b + cc) : zero;
+    const float4 w4 = a.dot_w ? *(const float4*)(a.dot_w + cc) : zero;
+    if (!on) v = zero;
+    if (P) {
+        float4 p = zero;
 #pragma unroll
         for (int k = 0; k < MAXS; ++k) { p.x += part[k].x; p.y += part[k].y; p.z += part[k].z; p.w += part[k].w; }
         if (on) {
-            if (a.pbias) { const float4 b4 = *(const float4*)(a.pbias + c); p.x += b4.x; p.y += b4.y; p.z += b4.z; p.w += b4.w; }
-            if (a.colscale) { const float4 s4 = *(const float4*)(a.colscale + c); p.x *= s4.x; p.y *= s4.y; p.z *= s4.z; p.w *= s4.w; }
+            p.x = (p.x + pb4.x) * s4.x; p.y = (p.y + pb4.y) * s4.y; p.z = (p.z + pb4.z) * s4.z; p.w = (p.w + pb4.w) * s4.w;
             v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
             *(float4*)(xr + c) = v;
         }
@@ -407,11 +413,10 @@ __global__ __launch_bounds__(256) void add_norm_kernel(AddNormArgs a) {
     const float rstd = 1.0f / sqrtf(block_sum4((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3), red, tid) / (float)a.D + a.eps);
     float dot = 0.f;
     if (on) {
-        const float4 g4 = *(const float4*)(a.g + c), b4 = *(const float4*)(a.b + c);
         const float y0 = d0 * rstd * g4.x + b4.x, y1 = d1 * rstd * g4.y + b4.y, y2 = d2 * rstd * g4.z + b4.z, y3 = d3 * rstd * g4.w + b4.w;
         if (a.H) *(float4*)(a.H + (long long)m * a.D + c) = make_float4(y0, y1, y2, y3);
         if (a.H32) *(float4*)(a.H32 + (long long)m * a.D + c) = make_float4(y0, y1, y2, y3);
-        if (a.dot_w) { const float4 w4 = *(const float4*)(a.dot_w + c); dot = (y0 * w4.x + y1 * w4.y) + (y2 * w4.z + y3 * w4.w); }
+        dot = (y0 * w4.x + y1 * w4.y) + (y2 * w4.z + y3 * w4.w);
     }
     if (a.dot_w) {
         dot = block_sum4(dot, red, tid);
@@ -424,7 +429,8 @@ void launch_add_norm(const AddNormArgs& a, hipStream_t s) {
     if (a.D % 4 || a.D > 1024 || (a.ldx & 3)) throw std::runtime_error("add_norm: width must be a multiple of 4 and <= 1024");
     if (a.P && (a.splits < 1 || a.splits > 16)) throw std::runtime_error("add_norm: 1..16 K-slices supported");
     dim3 grid(a.M), block(256);
-    hipLaunchKernelGGL(add_norm_kernel, grid, block, 0, s, a);
+    if (a.splits <= 8) hipLaunchKernelGGL(add_norm_kernel<8>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(add_norm_kernel<16>, grid, block, 0, s, a);
 }
 
 // ------------------------------------------------------------------ decode attention, one 4-wave block per (row, head)
