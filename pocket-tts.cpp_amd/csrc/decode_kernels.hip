@@ -102,6 +102,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r = lane & 15, g = lane >> 4;
+    // the epilogue's bias is requested with the first operands, not after the last product
+    const float bias_col = (a.bias && !a.P && tile_live) ? a.bias[nt * 16 + r] : 0.f;
 
     load_chunk(0);
     for (int c = 0; c < nchunks; ++c) {
@@ -158,8 +160,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
             if (a.P) {
                 a.P[((long long)blockIdx.y * a.M + row) * a.N + col] = v;
             } else {
-                if (a.bias) v += a.bias[col];
-                a.C[(long long)row * a.ldc + col] = act_dev(v, a.act);
+                a.C[(long long)row * a.ldc + col] = act_dev(v + bias_col, a.act);
             }
         }
     }
@@ -387,7 +388,38 @@ __global__ __launch_bounds__(256) void add_norm_kernel(AddNormArgs a) {
     const float* __restrict__ P = a.P;
     // every operand of the launch is requested here, before anything is waited for
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 v = *(const float4*)(xr + cc);
+    float4 v;
+    if (a.seq) {
+        // input projection of the LM (no bias): this thread's four output columns, K = L
+        const float* sq = a.seq + (long long)m * a.L;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.w_in_type == W_BF16) {
+            const __bf16* wr = (const __bf16*)a.w_in + (long long)cc * a.L;
+            for (int k = 0; k < a.L; k += 8) {
+                const float4 sa = *(const float4*)(sq + k), sb = *(const float4*)(sq + k + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x8 w8 = *(const bf16x8*)(wr + (long long)i * a.L + k);
+                    o[i] += ((float)w8[0] * sa.x + (float)w8[1] * sa.y) + ((float)w8[2] * sa.z + (float)w8[3] * sa.w) +
+                            ((float)w8[4] * sb.x + (float)w8[5] * sb.y) + ((float)w8[6] * sb.z + (float)w8[7] * sb.w);
+                }
+            }
+        } else {
+            const float* wr = (const float*)a.w_in + (long long)cc * a.L;
+            for (int k = 0; k < a.L; k += 4) {
+                const float4 sa = *(const float4*)(sq + k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 w4f = *(const float4*)(wr + (long long)i * a.L + k);
+                    o[i] += (w4f.x * sa.x + w4f.y * sa.y) + (w4f.z * sa.z + w4f.w * sa.w);
+                }
+            }
+        }
+        v = make_float4(o[0], o[1], o[2], o[3]);
+        if (on) *(float4*)(xr + c) = v;
+    } else {
+        v = *(const float4*)(xr + cc);
+    }
     float4 part[MAXS];
 #pragma unroll
     for (int k = 0; k < MAXS; ++k) part[k] = (P && k < a.splits) ? *(const float4*)(P + ((long long)k * a.M + m) * a.D + cc) : zero;
@@ -428,6 +460,7 @@ void launch_add_norm(const AddNormArgs& a, hipStream_t s) {
     if (a.M <= 0) return;
     if (a.D % 4 || a.D > 1024 || (a.ldx & 3)) throw std::runtime_error("add_norm: width must be a multiple of 4 and <= 1024");
     if (a.P && (a.splits < 1 || a.splits > 16)) throw std::runtime_error("add_norm: 1..16 K-slices supported");
+    if (a.seq && (!a.w_in || a.L <= 0 || (a.L & 7) || a.P)) throw std::runtime_error("add_norm: the projection prologue needs L % 8 == 0 and no K-slices");
     dim3 grid(a.M), block(256);
     if (a.splits <= 8) hipLaunchKernelGGL(add_norm_kernel<8>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(add_norm_kernel<16>, grid, block, 0, s, a);

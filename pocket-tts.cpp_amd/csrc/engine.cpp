@@ -784,13 +784,10 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         launch_prep_latent(seq_dev, b.seq_in.f(), B, s.latent, 0, hd_.bos, nullptr, b.st);
         seq_rows = b.seq_in.f();
     }
-    if (model_->lm_in_packed && s.latent % 4 == 0) {
-        SkinnyArgs g;
-        g.A = seq_rows; g.lda = s.latent; g.Wp = model_->lm_in_packed; g.wtype = model_->flow_wtype; g.M = B; g.N = D; g.K = s.latent;
-        g.C = b.x.f(); g.ldc = D;
-        launch_skinny_gemm(g, b.st);
-    } else {
-        const DevWeight& win = hd_.lm_in;
+    // the input projection (K = latent_dim, no bias) runs inside the first add & norm launch when its shape allows
+    const DevWeight& win = hd_.lm_in;
+    const bool proj_in_norm = s.latent % 8 == 0 && D % 4 == 0 && D <= 1024 && (win.wtype == W_BF16 || win.wtype == W_F32);
+    if (!proj_in_norm) {
         GemmArgs g;
         g.A = seq_rows; g.lda = s.latent; g.W = win.p; g.wtype = win.wtype; g.C = b.x.f(); g.ldc = D;
         g.M = B; g.N = D; g.K = s.latent; g.split_a = 1;
@@ -806,7 +803,11 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
     AddNormArgs an;
     an.X = b.x.f(); an.ldx = D; an.M = B; an.D = D; an.eps = s.lm_eps;
     an.g = hd_.lm[0].ln1g; an.b = hd_.lm[0].ln1b; an.H = b.h.f();
-    launch_add_norm(an, b.st);
+    {
+        AddNormArgs a0 = an;
+        if (proj_in_norm) { a0.seq = seq_rows; a0.w_in = win.p; a0.w_in_type = win.wtype; a0.L = s.latent; }
+        launch_add_norm(a0, b.st);
+    }
     const long long layer_stride = static_cast<long long>(B) * b.lm_cap * D;
     for (int l = 0; l < s.lm_layers; ++l) {
         const TfLayer& w = hd_.lm[l];

@@ -186,6 +186,8 @@ struct AddNormArgs {
     const float* dot_w = nullptr; const float* dot_b = nullptr; float* dot_out = nullptr;
     int* pos = nullptr; int pos_delta = 0;
     int M = 0, D = 0;
+    // optional prologue: X[m][:] = W_in[D][L] . seq[m][:L] (row-major W_in, f32 or bf16) instead of reading X; L % 8 == 0
+    const float* seq = nullptr; const void* w_in = nullptr; int w_in_type = W_F32; int L = 0;
 };
 void launch_add_norm(const AddNormArgs& a, hipStream_t s);
 
