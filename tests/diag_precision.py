@@ -1,7 +1,7 @@
 """Per-graph error of the GPU path (fp32 and bf16) against the oracle on a full-size synthetic pack."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pocket-tts.cpp_amd", "pyhost")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import ptts_pack as pp, ptts_lib, oracle_py
 
