@@ -472,14 +472,16 @@ void launch_add_norm(const AddNormArgs& a, hipStream_t s) {
 // softmaxes over its range and leaves (max, sum, unnormalised output) partials in LDS; wave 0 merges them and
 // adds the new token, whose rotated key and value never leave registers.  Every wave rotates q itself; wave 0
 // appends k, v to the cache.
-// bf16 cache with at most 64 keys per wave (the batched frame loop): lane (g, c) = (lane / 8, lane % 8) holds channels
-// 8c..8c+7 of keys g, g+8, ...: one 16-byte load per key for K and for V, a wave instruction covering eight whole
-// 128-byte rows, all 16 loads requested before anything waits on q.  Scores are reduced over the 8 channel lanes
+// bf16 cache (the batched frame loop): lane (g, c) = (lane / 8, lane % 8) holds channels 8c..8c+7 of keys g, g+8, ...:
+// one 16-byte load per key for K and for V, a wave instruction covering eight whole 128-byte rows, the 16 loads
+// of the wave's first 64 keys requested before anything waits on q.  Scores are reduced over the 8 channel lanes
 // by DPP, the softmax and P.V stay in registers in that same layout, and each 16-lane row leaves its own partial
-// (16 partials per workgroup), so nothing crosses a DPP row.  Other cases: lane per key for the scores, then
-// 4 key groups x 16 channel quads for P.V, one partial per wave.
+// (16 partials per workgroup), so nothing crosses a DPP row.  A wave with more than 64 keys (contexts beyond 256)
+// walks further blocks of 64 through the same registers under a running softmax.  The kernel is held to 128
+// VGPRs: a frame step launches four workgroups per CU and they must all be resident at once.
+// fp32 cache: lane per key for the scores, then 4 key groups x 16 channel quads for P.V, one partial per wave.
 template <bool KV16>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
+__global__ __launch_bounds__(256, 4) void attn_decode_kernel(AttnDecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
@@ -499,27 +501,30 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
         const float* rs = row + (long long)s * a.M * 3 * a.d;
         qv += rs[lane]; kv += rs[a.d + lane]; vv += rs[2 * a.d + lane];
     }
-    // fast path: every K and V element the wave needs is requested here.  Out-of-range keys re-read the wave's last
-    // key (their weight is zero below).
+    // fast path: the K and V elements of the wave's first 64 keys are requested here; later blocks of 64 keys reuse
+    // the same registers inside the loop below.  Out-of-range keys re-read the block's last key (their weight is
+    // zero below).
     bf16x8 kreg[8], vreg[8];
-    const bool early = KV16 && cnt > 0 && cnt <= 64;
+    const bool early = KV16 && cnt > 0;
     const int kg8 = lane >> 3, c8 = lane & 7;
-    const int ni = __builtin_amdgcn_readfirstlane((cnt + 7) >> 3);   // 8-key steps this wave needs
+    auto request_block = [&](int c0) {
+        const int cb = min(cnt - c0, 64);
+        const int nb = __builtin_amdgcn_readfirstlane((cb + 7) >> 3);   // 8-key steps of this block
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nb) {   // wave-uniform: whole instructions of out-of-range keys are not issued
+                const int jk = c0 + (kg8 + 8 * i < cb ? kg8 + 8 * i : cb - 1);
+                kreg[i] = *(const bf16x8*)((const __bf16*)a.kcache + cbase + (long long)((j0 + kb + jk) % a.cap) * a.d + 8 * c8);
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nb) {
+                const int jk = c0 + (kg8 + 8 * i < cb ? kg8 + 8 * i : cb - 1);
+                vreg[i] = *(const bf16x8*)((const __bf16*)a.vcache + cbase + (long long)((j0 + kb + jk) % a.cap) * a.d + 8 * c8);
+            }
+    };
     if constexpr (KV16) {
-        if (early) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i < ni) {   // wave-uniform: whole instructions of out-of-range keys are not issued
-                    const int jk = kg8 + 8 * i < cnt ? kg8 + 8 * i : cnt - 1;
-                    kreg[i] = *(const bf16x8*)((const __bf16*)a.kcache + cbase + (long long)((j0 + kb + jk) % a.cap) * a.d + 8 * c8);
-                }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i < ni) {
-                    const int jk = kg8 + 8 * i < cnt ? kg8 + 8 * i : cnt - 1;
-                    vreg[i] = *(const bf16x8*)((const __bf16*)a.vcache + cbase + (long long)((j0 + kb + jk) % a.cap) * a.d + 8 * c8);
-                }
-        }
+        if (early) request_block(0);
     }
     const float qo = __shfl_xor(qv, 1, 64), ko = __shfl_xor(kv, 1, 64);
     // pair (2i, 2i+1): even lane x*c - y*s, odd lane x*s + y*c, with x the even and y the odd element
@@ -551,31 +556,57 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     if constexpr (KV16) {
         if (early) {
             const float4 qa = *(const float4*)(qs + 8 * c8), qb = *(const float4*)(qs + 8 * c8 + 4);
+            // running softmax of this 16-lane row over the wave's blocks of 64 keys; the sum and the output stay
+            // per 8-lane group until the end.  The first block is straight-line code so that each score waits only
+            // for its own key's load; later blocks (contexts beyond 256 keys) run in the loop.
+            float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ls = 0.f, mr;
             float sv[8];
-            float mr = -INFINITY;
+            auto scores = [&](int cb, int nb) -> float {   // fills sv, returns the row's maximum
+                float bm = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                sv[i] = -INFINITY;
-                if (i >= ni) continue;
-                const bf16x8 k8 = kreg[i];
-                float d = ((qa.x * (float)k8[0] + qa.y * (float)k8[1]) + (qa.z * (float)k8[2] + qa.w * (float)k8[3])) +
-                          ((qb.x * (float)k8[4] + qb.y * (float)k8[5]) + (qb.z * (float)k8[6] + qb.w * (float)k8[7]));
-                d = dpp_add<0xB1>(d);    // + the other lane of the pair
-                d = dpp_add<0x4E>(d);    // + the other pair of the quad
-                d = dpp_add<0x141>(d);   // + the other quad of the 8 channel lanes
-                sv[i] = kg8 + 8 * i < cnt ? d * 0.125f : -INFINITY;
-                mr = fmaxf(mr, sv[i]);
+                for (int i = 0; i < 8; ++i) {
+                    sv[i] = -INFINITY;
+                    if (i >= nb) continue;
+                    const bf16x8 k8 = kreg[i];
+                    float d = ((qa.x * (float)k8[0] + qa.y * (float)k8[1]) + (qa.z * (float)k8[2] + qa.w * (float)k8[3])) +
+                              ((qb.x * (float)k8[4] + qb.y * (float)k8[5]) + (qb.z * (float)k8[6] + qb.w * (float)k8[7]));
+                    d = dpp_add<0xB1>(d);    // + the other lane of the pair
+                    d = dpp_add<0x4E>(d);    // + the other pair of the quad
+                    d = dpp_add<0x141>(d);   // + the other quad of the 8 channel lanes
+                    sv[i] = kg8 + 8 * i < cb ? d * 0.125f : -INFINITY;
+                    bm = fmaxf(bm, sv[i]);
+                }
+                return fmaxf(bm, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, bm), 0x128, 0xF, 0xF, true)));   // row_ror:8
+            };
+            auto weigh = [&](int nb) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (i >= nb) continue;
+                    const float pw = sv[i] == -INFINITY ? 0.f : expf(sv[i] - mr);
+                    ls += pw;
+                    const bf16x8 v8 = vreg[i];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) o8[c] += pw * (float)v8[c];
+                }
+            };
+            {
+                const int cb = min(cnt, 64);
+                const int nb = __builtin_amdgcn_readfirstlane((cb + 7) >> 3);
+                mr = scores(cb, nb);
+                weigh(nb);
             }
-            mr = fmaxf(mr, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mr), 0x128, 0xF, 0xF, true)));   // row_ror:8
-            float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ls = 0.f;
+            for (int c0 = 64; c0 < cnt; c0 += 64) {
+                const int cb = min(cnt - c0, 64);
+                const int nb = __builtin_amdgcn_readfirstlane((cb + 7) >> 3);
+                request_block(c0);
+                const float mn = fmaxf(mr, scores(cb, nb));
+                // rescale what earlier blocks left (a row without keys so far scales by zero, not by exp(nan))
+                const float rs = mr == -INFINITY ? 0.f : expf(mr - mn);
+                ls *= rs;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i >= ni) continue;
-                const float pw = sv[i] == -INFINITY ? 0.f : expf(sv[i] - mr);
-                ls += pw;
-                const bf16x8 v8 = vreg[i];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) o8[c] += pw * (float)v8[c];
+                for (int c = 0; c < 8; ++c) o8[c] *= rs;
+                mr = mn;
+                weigh(nb);
             }
             ls = dpp_add<0x128>(ls);
 #pragma unroll

@@ -144,8 +144,8 @@ static void bench_flow(int B) {
                 h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
 }
 
-static void bench_attn_decode(int ctx, int kv16) {
-    const int M = 64, d = 1024, heads = 16, cap = 256, splits = 4;
+static void bench_attn_decode(int ctx, int kv16, int cap = 256) {
+    const int M = 64, d = 1024, heads = 16, splits = 4;
     AttnDecodeArgs a;
     a.qkv = (const float*)dalloc((size_t)splits * M * 3 * d * 4); a.qkv_splits = splits;
     a.kcache = dalloc((size_t)M * cap * d * 4); a.vcache = dalloc((size_t)M * cap * d * 4); a.kv16 = kv16;
@@ -154,7 +154,9 @@ static void bench_attn_decode(int ctx, int kv16) {
     a.pos = dp; a.M = M; a.d = d; a.heads = heads; a.cap = cap;
     a.cos_tab = (const float*)dalloc(1024 * 32 * 4); a.sin_tab = (const float*)dalloc(1024 * 32 * 4); a.tab_len = 1024;
     a.out = (float*)dalloc((size_t)M * d * 4, 0);
-    time_it(kv16 ? "attn_decode_bf16" : "attn_decode_f32", 300, [&](hipStream_t s) { launch_attn_decode(a, s); },
+    char nm[64];
+    std::snprintf(nm, sizeof nm, "attn_%s_ctx%d", kv16 ? "bf16" : "f32", ctx);
+    time_it(nm, 300, [&](hipStream_t s) { launch_attn_decode(a, s); },
             2.0 * M * ctx * d * (kv16 ? 2 : 4) + (double)splits * M * 3 * d * 4, 4.0 * M * ctx * d);
 }
 
@@ -230,7 +232,7 @@ int main(int argc, char** argv) {
                 std::snprintf(nm, sizeof nm, "ff2 mt%d k%d sp16", mt, kch); bench_skinny(nm, 64, 1024, 4096, 16, mt, kch);
             }
     }
-    if (want("attn_decode")) { bench_attn_decode(156, 1); bench_attn_decode(156, 0); }
+    if (want("attn_decode")) { bench_attn_decode(156, 1); bench_attn_decode(156, 0); bench_attn_decode(250, 1, 640); bench_attn_decode(300, 1, 640); bench_attn_decode(500, 1, 640); }
     if (want("flow")) bench_flow(64);
     return 0;
 }

@@ -61,6 +61,33 @@ def test_lm_prefill_and_steps(ptts, packs, oracle_mod, name, precision, tol):
     st.close(); eng.close()
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", F32_TOL), ("bf16", BF16_TOL * 5)])
+def test_lm_steps_long_ragged_context(ptts, packs, oracle_mod, precision, tol):
+    """Decode attention beyond 64 keys per wave (a bf16 cache walks its range in blocks of 64 with a running softmax):
+    contexts of 41, 330 and 650 rows side by side, checked on every step."""
+    eng, spec = _engine(ptts, packs, "small", precision, max_frames=700, max_text_tokens=64)
+    o = oracle_mod.Oracle(packs["small"][0])
+    rng = np.random.default_rng(11)
+    B, S = 3, 4
+    voices = [(rng.standard_normal((nv, spec.d_model)) * 0.5).astype(np.float32) for nv in (1, 290, 610)]
+    text = o.text_conditioner(rng.integers(0, spec.vocab, 40))
+    seq = rng.standard_normal((S, B, spec.latent_dim)).astype(np.float32)
+    seq[0] = np.nan
+    st = eng.state(B)
+    ost = [o.lm_state(1024) for _ in range(B)]
+    for b in range(B):
+        eng.lm_prefill(st, b, voices[b]); eng.lm_prefill(st, b, text)
+        o.lm_main(ost[b], None, voices[b]); o.lm_main(ost[b], None, text)
+    worst = 0.0
+    for s in range(S):
+        cond, eos = eng.lm_step(st, seq[s])
+        for b in range(B):
+            oc, oe = o.lm_main(ost[b], seq[s, b:b + 1], None)
+            worst = max(worst, np.abs(cond[b] - oc).max(), abs(eos[b] - oe))
+    assert worst < tol, worst
+    st.close(); eng.close()
+
+
 @pytest.mark.parametrize("name,precision,tol,rows", [("tiny", "fp32", F32_TOL, 5), ("small", "fp32", F32_TOL, 37), ("small", "bf16", BF16_TOL * 5, 16)])
 def test_flow_euler(ptts, packs, oracle_mod, name, precision, tol, rows):
     eng, spec = _engine(ptts, packs, name, precision, lsd_steps=10)
