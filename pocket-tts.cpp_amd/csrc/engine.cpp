@@ -687,6 +687,15 @@ void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc,
     }
 }
 
+// K-slices for a split-K product: about 256 deep each, at most 8, dividing K into k-step multiples.
+static int pick_splits(int K, int kstep) {
+    int s = K / 256;
+    if (s < 1) s = 1;
+    if (s > 8) s = 8;
+    while (s > 1 && (K % s != 0 || (K / s) % kstep != 0)) --s;
+    return s;
+}
+
 // adv_dev / adv_host (optional): per-slot position advance when the nb x rpb rows are padded to a common length.
 void Engine::lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* adv_dev, const int* adv_host) {
     const Spec& s = spec();
@@ -694,8 +703,10 @@ void Engine::lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* 
         if (b.lm_pos_host[slot0 + i] + rpb > b.lm_cap)
             throw std::runtime_error("LM context exceeds the KV-cache capacity (voice + text + frames too long)");
     b.ensure_rows(static_cast<size_t>(nb) * rpb, s.d_model, s.lm_ffn);
-    if (model_->lm_wtype == W_I8) {
-        lm_rows_q8(b, slot0, nb, rpb, X);
+    // int8 matrices exist only in the skinny kernels' layout; float and bf16 passes of up to 128 rows (one utterance's
+    // voice and text) go the same way, because a tiled GEMM of that height fills 16 to 48 of the 256 CUs
+    if (model_->lm_wtype == W_I8 || (nb * rpb <= 128 && !std::getenv("POCKET_TTS_NO_SKINNY_PREFILL"))) {
+        lm_rows_skinny(b, slot0, nb, rpb, X);
         if (adv_dev) launch_advance_pos_vec(b.lm_pos.as<int>() + slot0, adv_dev, nb, b.st);
         else launch_advance_pos(b.lm_pos.as<int>() + slot0, nb, rpb, b.st);
         for (int i = 0; i < nb; ++i) b.lm_pos_host[slot0 + i] += adv_host ? adv_host[i] : rpb;
@@ -710,15 +721,19 @@ void Engine::lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* 
     for (int i = 0; i < nb; ++i) b.lm_pos_host[slot0 + i] += adv_host ? adv_host[i] : rpb;
 }
 
-// Multi-row LM pass with the int8 layer matrices: the decode step's kernels (skinny product, add & norm) over
-// M = nb * rpb rows, with the multi-row rotate/append and tiled attention in place of the one-row kernel.
-void Engine::lm_rows_q8(Batch& b, int slot0, int nb, int rpb, float* X) {
+// Multi-row LM pass on the decode step's kernels (skinny product, add & norm) over M = nb * rpb rows, with the
+// multi-row rotate/append and tiled attention in place of the one-row kernel.  Short passes cut the output and
+// FFN-2 products into K-slices so that the launch has enough workgroups; the add & norm that follows sums them.
+void Engine::lm_rows_skinny(Batch& b, int slot0, int nb, int rpb, float* X) {
     const Spec& s = spec();
     const int D = s.d_model, F = s.lm_ffn, M = nb * rpb;
+    const int wt = model_->lm_wtype, kstep = wt == W_I8 ? 64 : wt == W_BF16 ? 32 : 16;
+    const int s_out = M <= 128 ? pick_splits(D, kstep) : 1, s_ff2 = M <= 128 ? pick_splits(F, kstep) : 1;
     hipStream_t st = b.st;
-    if (b.pre_partial.bytes < static_cast<size_t>(M) * D * 4) {
+    const size_t need = static_cast<size_t>(std::max(s_out, s_ff2)) * M * D * 4;
+    if (b.pre_partial.bytes < need) {
         PTTS_HIP(hipDeviceSynchronize());
-        b.pre_partial.alloc(static_cast<size_t>(M) * D * 4);
+        b.pre_partial.alloc(need);
     }
     const long long layer_stride = static_cast<long long>(b.B) * b.lm_cap * D;
     AddNormArgs an;
@@ -729,7 +744,7 @@ void Engine::lm_rows_q8(Batch& b, int slot0, int nb, int rpb, float* X) {
         const TfLayer& w = hd_.lm[l];
         const Model::PackedLayer& pw = model_->lm_packed[l];
         SkinnyArgs q;
-        q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.wtype = W_I8; q.wscale = pw.s_qkv; q.M = M; q.N = 3 * D; q.K = D; q.C = b.qkv.f(); q.ldc = 3 * D;
+        q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.wtype = wt; q.wscale = pw.s_qkv; q.M = M; q.N = 3 * D; q.K = D; q.C = b.qkv.f(); q.ldc = 3 * D;
         launch_skinny_gemm(q, st);
         RopeAppendArgs r;
         const long long kv_off = static_cast<long long>(l) * layer_stride * (b.kv16 ? 2 : 4);
@@ -742,33 +757,24 @@ void Engine::lm_rows_q8(Batch& b, int slot0, int nb, int rpb, float* X) {
         at.M = M; at.d = D; at.heads = s.lm_heads; at.cap = b.lm_cap; at.window = 0;
         launch_attention(at, st);
         SkinnyArgs o;
-        o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.wtype = W_I8; o.wscale = pw.s_out; o.M = M; o.N = D; o.K = D; o.splits = 1; o.P = b.pre_partial.f();
+        o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.wtype = wt; o.wscale = pw.s_out; o.M = M; o.N = D; o.K = D; o.splits = s_out; o.P = b.pre_partial.f();
         launch_skinny_gemm(o, st);
         AddNormArgs a1 = an;
-        a1.P = b.pre_partial.f(); a1.splits = 1; a1.colscale = w.ls1; a1.g = w.ln2g; a1.b = w.ln2b;
+        a1.P = b.pre_partial.f(); a1.splits = s_out; a1.colscale = w.ls1; a1.g = w.ln2g; a1.b = w.ln2b;
         launch_add_norm(a1, st);
         SkinnyArgs f1;
-        f1.A = b.h.f(); f1.lda = D; f1.Wp = pw.ff1; f1.wtype = W_I8; f1.wscale = pw.s_ff1; f1.M = M; f1.N = F; f1.K = D; f1.act = ACT_GELU;
+        f1.A = b.h.f(); f1.lda = D; f1.Wp = pw.ff1; f1.wtype = wt; f1.wscale = pw.s_ff1; f1.M = M; f1.N = F; f1.K = D; f1.act = ACT_GELU;
         f1.C = b.ff.f(); f1.ldc = F;
         launch_skinny_gemm(f1, st);
         SkinnyArgs f2;
-        f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.wtype = W_I8; f2.wscale = pw.s_ff2; f2.M = M; f2.N = D; f2.K = F; f2.splits = 1; f2.P = b.pre_partial.f();
+        f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.wtype = wt; f2.wscale = pw.s_ff2; f2.M = M; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.pre_partial.f();
         launch_skinny_gemm(f2, st);
         AddNormArgs a2 = an;
-        a2.P = b.pre_partial.f(); a2.splits = 1; a2.colscale = w.ls2;
+        a2.P = b.pre_partial.f(); a2.splits = s_ff2; a2.colscale = w.ls2;
         if (l + 1 < s.lm_layers) { a2.g = hd_.lm[l + 1].ln1g; a2.b = hd_.lm[l + 1].ln1b; }
         else { a2.g = nullptr; a2.b = nullptr; a2.H = nullptr; }
         launch_add_norm(a2, st);
     }
-}
-
-// K-slices for a split-K product: about 256 deep each, at most 8, dividing K into k-step multiples.
-static int pick_splits(int K, int kstep) {
-    int s = K / 256;
-    if (s < 1) s = 1;
-    if (s > 8) s = 8;
-    while (s > 1 && (K % s != 0 || (K / s) % kstep != 0)) --s;
-    return s;
 }
 
 // sequence[B][latent] (NaN = BOS) -> conditioning[B][d_model], eos[B]   (src/pocket_tts.cpp:323-411, decode shape)

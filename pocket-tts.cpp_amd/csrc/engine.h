@@ -199,7 +199,7 @@ private:
     void frame_body(Batch& b, int parity);
     void ensure_frame_graph(Batch& b);
     void lm_bookkeeping(Batch& b);
-    void lm_rows_q8(Batch& b, int slot0, int nb, int rpb, float* X);
+    void lm_rows_skinny(Batch& b, int slot0, int nb, int rpb, float* X);
     void lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* adv_dev = nullptr, const int* adv_host = nullptr);
     // prepped: seq_dev already holds the BOS embedding where the reference passes NaN (no preparation launch)
     void lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev, bool prepped = false);

@@ -848,7 +848,8 @@ constexpr int kMaxFlowSplit = 8;
 static void flow_head_shape(int C, int B, bool bf, int& G, int& rpg) {
     G = 4; rpg = 16;
     if (bf && C == 512 && B > 4) rpg = 4;   // measured at B = 64: 4 x 16 -> 627 us per chain, 4 x 4 -> 578 us, 8 x any -> 670+ us
-    if (const char* e = std::getenv("FLOW_HEAD_SPLIT")) G = std::atoi(e) == 8 && bf && C == 512 ? 8 : 4;
+    if (!bf && C == 512 && B <= 8) G = 8;   // a streaming call's single row: 877 us per chain with 4 slices of float weights, 664 us with 8
+    if (const char* e = std::getenv("FLOW_HEAD_SPLIT")) G = std::atoi(e) == 8 && C == 512 ? 8 : 4;
     if (const char* e = std::getenv("FLOW_HEAD_ROWS")) { const int r = std::atoi(e); if (r == 1 || r == 2 || r == 4 || r == 8 || r == 16) rpg = r; }
 }
 
@@ -1000,6 +1001,7 @@ void launch_flow_head(const FlowHeadArgs& a, hipStream_t s) {
             else if (bf && rpg <= 8 && !std::getenv("FLOW_HEAD_NO_FUSE")) run_chain<__bf16, 512, true, 4, 1, true>(a, s, rpg);
             else if (bf && rpg <= 8) run_chain<__bf16, 512, true, 4, 1>(a, s, rpg);
             else if (bf) run_chain<__bf16, 512, true>(a, s, rpg);
+            else if (!bf && G == 8) run_chain<float, 512, false, 8>(a, s, rpg);
             else run_chain<float, 512, false>(a, s, rpg);
             break;
         case 1024: bf ? run_chain<__bf16, 1024, false>(a, s, rpg) : run_chain<float, 1024, false>(a, s, rpg); break;

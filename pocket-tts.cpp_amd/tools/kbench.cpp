@@ -115,11 +115,13 @@ static void bench_gemm(const char* name, int M, int N, int K, int split_a, int l
 }
 
 static void bench_flow(int B) {
+    const char* wenv = std::getenv("KB_FLOW_WTYPE");
+    const int W_T = wenv && !std::strcmp(wenv, "f32") ? W_F32 : W_BF16;
     const int C = 512, L = 32, nb = std::getenv("KB_FLOW_BLOCKS") ? std::atoi(std::getenv("KB_FLOW_BLOCKS")) : 6, steps = 10, mw = nb * 3 * C + 2 * C;
     FlowHostTabs tabs;
     for (int i = 0; i < nb; ++i) {
-        tabs.w_fc1.push_back(packed_weight(C, C, W_BF16));
-        tabs.w_fc2.push_back(packed_weight(C, C, W_BF16));
+        tabs.w_fc1.push_back(packed_weight(C, C, W_T));
+        tabs.w_fc2.push_back(packed_weight(C, C, W_T));
         tabs.b_fc1.push_back((const float*)dalloc(C * 4)); tabs.b_fc2.push_back((const float*)dalloc(C * 4));
         tabs.ln_g.push_back((const float*)dalloc(C * 4)); tabs.ln_b.push_back((const float*)dalloc(C * 4));
     }
@@ -128,10 +130,10 @@ static void bench_flow(int B) {
     a.x_out = (float*)dalloc((size_t)B * L * 4, 0);
     a.mods = (const float*)dalloc((size_t)steps * B * mw * 4);
     a.B = B; a.L = L; a.C = C; a.blocks = nb; a.steps = steps; a.mod_width = mw;
-    a.w_in = packed_weight(C, L, W_BF16); a.b_in = (const float*)dalloc(C * 4);
-    a.w_out = packed_weight(L, C, W_BF16); a.b_out = (const float*)dalloc(L * 4);
-    a.host_tabs = &tabs; a.workspace = (float*)dalloc(flow_head_workspace_bytes(B, C, W_BF16), 0); a.wtype = W_BF16;
-    flow_head_prepare(C, W_BF16);
+    a.w_in = packed_weight(C, L, W_T); a.b_in = (const float*)dalloc(C * 4);
+    a.w_out = packed_weight(L, C, W_T); a.b_out = (const float*)dalloc(L * 4);
+    a.host_tabs = &tabs; a.workspace = (float*)dalloc(flow_head_workspace_bytes(B, C, W_T), 0); a.wtype = W_T;
+    flow_head_prepare(C, W_T);
     const double us = time_it("flow_chain", 30, [&](hipStream_t s) { launch_flow_head(a, s); }, 0, 2.0 * B * steps * (2.0 * L * C + nb * 2.0 * C * C));
     std::printf("   = %.2f us per launch over %d launches\n", us / (steps * (nb + 1)), steps * (nb + 1));
     long long* cyc = (long long*)dalloc(64, 0);
@@ -233,6 +235,6 @@ int main(int argc, char** argv) {
             }
     }
     if (want("attn_decode")) { bench_attn_decode(156, 1); bench_attn_decode(156, 0); bench_attn_decode(250, 1, 640); bench_attn_decode(300, 1, 640); bench_attn_decode(500, 1, 640); }
-    if (want("flow")) bench_flow(64);
+    if (want("flow")) bench_flow(std::getenv("KB_FLOW_B") ? std::atoi(std::getenv("KB_FLOW_B")) : 64);
     return 0;
 }
