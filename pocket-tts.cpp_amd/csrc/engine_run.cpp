@@ -392,9 +392,23 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
     std::vector<std::mt19937> rngs;
     rngs.emplace_back(rng_());
     const bool any_noise = opt_.temperature > 0 || utt.noise;
-    for (int i = 0; i < L; ++i) b.h_x0[i] = std::numeric_limits<float>::quiet_NaN();
-    PTTS_HIP(hipMemcpyAsync(b.xcur.p, b.h_x0, static_cast<size_t>(L) * 4, hipMemcpyHostToDevice, stream_));
-    PTTS_HIP(hipStreamSynchronize(stream_));
+    // Same frame body as the batched loop (one graph launch per frame): the EOS logit reaches mapped host memory from
+    // inside the flow phase, the new latent is filed under its frame index, and nothing else leaves the device.
+    hipStream_t st = b.st;
+    PTTS_HIP(hipMemsetAsync(b.step_dev.p, 0, 4, st));
+    *b.h_flag = 0;
+    for (int i = 0; i < L; ++i) b.h_x0[i] = std::numeric_limits<float>::quiet_NaN();   // BOS marker (:721)
+    PTTS_HIP(hipMemcpyAsync(b.seq_in.p, b.h_x0, static_cast<size_t>(L) * 4, hipMemcpyHostToDevice, st));
+    launch_prep_latent(b.seq_in.f(), b.xcur.f(), 1, L, 0, hd_.bos, nullptr, st);
+    b.x0_src = b.x0.f(); b.x0_stride = L; b.x0_step_stride = 0;   // start points arrive frame by frame
+    if (!any_noise) PTTS_HIP(hipMemsetAsync(b.x0.p, 0, static_cast<size_t>(L) * 4, st));
+    const bool graph = use_graph_ && !timing_;
+    if (graph) {
+        const std::vector<int> keep = b.lm_pos_host;
+        ensure_frame_graph(b);
+        b.lm_pos_host = keep;
+    }
+    PTTS_HIP(hipStreamSynchronize(st));
 
     std::vector<float> chunk_audio;
     auto flush = [&](int first, int count, bool is_final) {
@@ -415,20 +429,21 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
     for (int step = 0; step < opt_.max_frames; ++step) {
         if (poll_cancel && cancel_flag && cancel_flag->load()) break;                      // :745-750
         lm_bookkeeping(b);
-        lm_step_dev(b, b.xcur.f(), b.cond.f(), b.eos.f());                                 // :753
-        PTTS_HIP(hipMemcpyAsync(b.h_eos, b.eos.p, 4, hipMemcpyDeviceToHost, stream_));
-        PTTS_HIP(hipStreamSynchronize(stream_));
-        const float e = b.h_eos[0];
-        if (capture) capture->eos.push_back(e);
-        if (e > kEosThreshold && eos_step < 0) eos_step = step;                            // :758
-        if (eos_step >= 0 && step >= eos_step + opt_.frames_after_eos) break;              // :763
         if (any_noise) {
             fill_noise(rngs, one, step, b.h_x0);
-            PTTS_HIP(hipMemcpyAsync(b.x0.p, b.h_x0, static_cast<size_t>(L) * 4, hipMemcpyHostToDevice, stream_));
+            PTTS_HIP(hipMemcpyAsync(b.x0.p, b.h_x0, static_cast<size_t>(L) * 4, hipMemcpyHostToDevice, st));
         }
-        flow_dev(b, b.cond.f(), b.x0.f(), L, b.xcur.f(), 1);                               // :777-784
-        PTTS_HIP(hipMemcpyAsync(b.latents.f() + static_cast<size_t>(step) * L, b.xcur.p, static_cast<size_t>(L) * 4, hipMemcpyDeviceToDevice, stream_));
-        if (any_noise) PTTS_HIP(hipStreamSynchronize(stream_));
+        if (graph) PTTS_HIP(hipGraphLaunch(b.frame_exec[step & 1], st));                     // :753, :777-784
+        else frame_body(b, step & 1);
+        for (unsigned spins = 1; __atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < step + 1; ++spins) {
+            if ((spins & 0xffff) == 0 && hipStreamQuery(st) == hipSuccess && __atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < step + 1)
+                throw std::runtime_error("frame finished without publishing its EOS logit");
+        }
+        const float e = b.h_eos_all[step];
+        if (capture) capture->eos.push_back(e);
+        if (e > kEosThreshold && eos_step < 0) eos_step = step;                            // :758
+        if (eos_step >= 0 && step >= eos_step + opt_.frames_after_eos) break;              // :763 (this step's flow output is not used)
+        if (any_noise) PTTS_HIP(hipStreamSynchronize(st));                                 // h_x0 is rewritten next frame
         ++frames; ++pending;
         if (pending >= chunk_frames) {                                                     // :790 (the second clause cannot hold here)
             flush(frames - pending, pending, false);

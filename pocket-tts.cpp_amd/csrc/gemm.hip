@@ -219,7 +219,9 @@ void launch_gemm(const GemmArgs& a, hipStream_t s) {
         throw std::runtime_error("gemm: K, lda and batch stride must be multiples of 4 floats and pointers 16-byte aligned");
     if (a.wtype == W_BF16 && (a.K & 7)) throw std::runtime_error("gemm: bf16 weights need K % 8 == 0");
     if (a.rpb <= 0) throw std::runtime_error("gemm: rows per batch must be positive");
-    const bool big = a.M > 256 && a.N >= 128;
+    // 128 x 128 tiles only when they still give most CUs a workgroup; a short product (one utterance's chunk in the
+    // decoder) runs on 64 x 64 tiles, four times as many workgroups
+    const bool big = a.M > 256 && a.N >= 128 && (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) >= 192;
     dim3 block(256);
     if (a.wtype == W_BF16) {
         if (big) {
