@@ -967,7 +967,7 @@ void flow_head_prepare(int C, int wtype) {
                 prepare_chain<__bf16, 512, true>(); prepare_chain<__bf16, 512, true, 4, 1>(); prepare_chain<__bf16, 512, true, 8, 1>();
                 set_lds_limit((const void*)flow_block_kernel<__bf16, 512, 4, 32, true, 1, true>, 128 * 1024);
             }
-            else prepare_chain<float, 512, false>();
+            else { prepare_chain<float, 512, false>(); prepare_chain<float, 512, false, 8>(); }
             break;
         case 1024: bf ? prepare_chain<__bf16, 1024, false>() : prepare_chain<float, 1024, false>(); break;
         default: throw std::runtime_error("flow head: flow_dim must be 128, 256, 512 or 1024");
