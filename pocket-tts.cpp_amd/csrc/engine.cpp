@@ -186,6 +186,15 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
             ada_packed = extra_.back().p;
         }
     }
+    {   // the voice encoder always runs on f32 weights
+        const HostTensor& t = pack.get("enc.down.w");
+        if (t.shape.size() == 2 && t.shape[0] % 16 == 0 && t.shape[1] % 16 == 0) {
+            auto bytes = pack_flow_weight(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), W_F32);
+            extra_.emplace_back(bytes.size());
+            PTTS_HIP(hipMemcpy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+            enc_ds_packed = extra_.back().p;
+        }
+    }
     for (int i = 0; i < s.lm_layers; ++i) {
         std::string p = "lm.l" + std::to_string(i) + ".";
         PackedLayer pl;

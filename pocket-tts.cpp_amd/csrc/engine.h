@@ -69,6 +69,7 @@ public:
     int lm_wtype = W_F32;        // weight type of lm_packed (W_I8 in int8 mode)
     int flow_block_wtype = W_F32;
     std::vector<PackedLayer> lm_packed;
+    const void* enc_ds_packed = nullptr;   // voice encoder's down-sampling matrix, fragment-major f32 (K-slice product of short clips)
     const void* flow_cond_packed = nullptr;
     const void* lm_in_packed = nullptr;  // LM input projection, fragment-major (null when its shape does not tile)
     const void* ada_packed = nullptr;   // stacked adaLN matrix, fragment-major (null when its shape does not tile)
@@ -232,6 +233,7 @@ private:
     std::recursive_mutex call_mu_;
     std::mt19937 rng_;
     DevBuf flow_te_;  // [lsd_steps][C] averaged time embeddings of the fixed (s_j, t_j) grid
+    DevBuf enc_arena_;   // every buffer of a voice-encoder pass, kept between calls
     std::map<std::pair<int, int>, std::unique_ptr<Batch>> batch_pool_;   // (rows, lane)
     std::vector<hipStream_t> lane_streams_;     // lane 0 = stream_
     std::vector<hipEvent_t> lane_events_;
@@ -293,7 +295,7 @@ public:
     // flow scratch
     DevBuf cemb, ymod, mods, flow_ws;
     DevBuf partial;   // split-K slabs of the decode step [splits][B][d_model] f32
-    DevBuf pre_partial;   // one slab [rows][d_model] for the int8 prefill pass
+    DevBuf pre_partial;   // K-slice slabs [splits][rows][d_model] of a prefill pass on the skinny kernels
     // audio out
     DevBuf audio;
     // staged inputs / outputs of a whole batch (Engine::stage / run_staged)

@@ -476,70 +476,123 @@ std::vector<float> Engine::encode_voice(const float* audio, int S) {
     const Spec& s = spec();
     if (S <= 0) throw std::runtime_error("voice clip is empty");
     const int M = s.mimi_dim, U = s.upsample, D = s.d_model, rk = s.res_kernel, lk = s.last_kernel;
-    auto zeros = [&](size_t floats) {
-        DevBuf d(floats * 4);
-        PTTS_HIP(hipMemsetAsync(d.p, 0, d.bytes, stream_));
-        return d;
+    const int ds_splits = 8;
+    // Every buffer of the pass is a slice of one arena that is kept between calls (a clip is encoded without a
+    // device allocation or a stream synchronisation before the result is copied out).  First the sizes, in the
+    // order the slices are taken below.
+    auto rounded = [](size_t floats) { return (floats * 4 + 255) & ~static_cast<size_t>(255); };
+    size_t need = rounded(S);
+    {
+        int c = s.n_filters, T = S;
+        need += rounded(static_cast<size_t>(T) * c) + rounded(static_cast<size_t>(rk - 1 + T) * c);
+        for (int i = 0; i < 3; ++i) {
+            const int r = s.ratios[2 - i], To = (T + r - 1) / r, Tpad = To * r, pn = i < 2 ? rk - 1 : lk - 1;
+            need += rounded(static_cast<size_t>(T) * (c / 2)) + rounded(static_cast<size_t>(r + Tpad) * c) +
+                    rounded(static_cast<size_t>(To) * 2 * c) + rounded(static_cast<size_t>(pn + To) * 2 * c);
+            T = To; c *= 2;
+        }
+        if (T > 16000) throw std::runtime_error("voice clip too long for the encoder attention buffer");
+        if (T > model_->mimi_tab_len) throw std::runtime_error("voice clip exceeds the rotary table");
+        const int Nv = (T + U - 1) / U, Tpad = Nv * U;
+        const size_t TM = static_cast<size_t>(T) * M;
+        need += rounded(TM) + 2 * rounded(static_cast<size_t>(s.mimi_layers) * TM) + rounded(1) + 3 * rounded(TM) + rounded(3 * TM) +
+                rounded(static_cast<size_t>(T) * s.mimi_ffn) + rounded(static_cast<size_t>(U + Tpad) * M) +
+                rounded(static_cast<size_t>(Nv) * M) + rounded(static_cast<size_t>(Nv) * D) + rounded(static_cast<size_t>(ds_splits) * Nv * M);
+    }
+    if (enc_arena_.bytes < need) {
+        PTTS_HIP(hipStreamSynchronize(stream_));
+        enc_arena_.alloc(need);
+    }
+    size_t top = 0;
+    auto take = [&](size_t floats, bool zero = false) -> float* {
+        const size_t n = rounded(floats);
+        if (top + n > enc_arena_.bytes) throw std::runtime_error("voice encoder arena sized too small");
+        float* p = reinterpret_cast<float*>(static_cast<unsigned char*>(enc_arena_.p) + top);
+        top += n;
+        if (zero) PTTS_HIP(hipMemsetAsync(p, 0, floats * 4, stream_));
+        return p;
     };
-    DevBuf dau(static_cast<size_t>(S) * 4);
-    PTTS_HIP(hipMemcpyAsync(dau.p, audio, static_cast<size_t>(S) * 4, hipMemcpyHostToDevice, stream_));
+    float* dau = take(S);
+    PTTS_HIP(hipMemcpyAsync(dau, audio, static_cast<size_t>(S) * 4, hipMemcpyHostToDevice, stream_));
     int c = s.n_filters, T = S;
-    DevBuf xraw(static_cast<size_t>(T) * c * 4);
-    DevBuf xe = zeros(static_cast<size_t>(rk - 1 + T) * c);
-    launch_conv_from_mono(dau.f(), 0, nullptr, T, s.kernel, c, hd_.enc_conv0_w, hd_.enc_conv0_b, xraw.f(), 0,
-                          xe.f() + static_cast<size_t>(rk - 1) * c, 0, 1, stream_);
+    float* xraw = take(static_cast<size_t>(T) * c);
+    float* xe = take(static_cast<size_t>(rk - 1 + T) * c);
+    PTTS_HIP(hipMemsetAsync(xe, 0, static_cast<size_t>(rk - 1) * c * 4, stream_));   // left padding of the causal convolution
+    launch_conv_from_mono(dau, 0, nullptr, T, s.kernel, c, hd_.enc_conv0_w, hd_.enc_conv0_b, xraw, 0,
+                          xe + static_cast<size_t>(rk - 1) * c, 0, 1, stream_);
     for (int i = 0; i < 3; ++i) {
         const int r = s.ratios[2 - i], To = (T + r - 1) / r, Tpad = To * r;
-        DevBuf h1(static_cast<size_t>(T) * (c / 2) * 4);
+        float* h1 = take(static_cast<size_t>(T) * (c / 2));
         GemmArgs c1;
-        c1.A = xe.f(); c1.lda = c; c1.W = hd_.enc_c1[i].p; c1.wtype = hd_.enc_c1[i].wtype; c1.bias = hd_.enc_c1_b[i];
-        c1.M = T; c1.N = c / 2; c1.K = rk * c; c1.C = h1.f(); c1.ldc = c / 2; c1.c_act = ACT_ELU;
+        c1.A = xe; c1.lda = c; c1.W = hd_.enc_c1[i].p; c1.wtype = hd_.enc_c1[i].wtype; c1.bias = hd_.enc_c1_b[i];
+        c1.M = T; c1.N = c / 2; c1.K = rk * c; c1.C = h1; c1.ldc = c / 2; c1.c_act = ACT_ELU;
         launch_gemm(c1, stream_);
-        DevBuf ye = zeros(static_cast<size_t>(r + Tpad) * c);
+        // rows [r, r + T) are written by the product below; the padding before and after them stays zero
+        float* ye = take(static_cast<size_t>(r + Tpad) * c);
+        PTTS_HIP(hipMemsetAsync(ye, 0, static_cast<size_t>(r) * c * 4, stream_));
+        if (Tpad > T) PTTS_HIP(hipMemsetAsync(ye + static_cast<size_t>(r + T) * c, 0, static_cast<size_t>(Tpad - T) * c * 4, stream_));
         GemmArgs c2;
-        c2.A = h1.f(); c2.lda = c / 2; c2.W = hd_.enc_c2[i].p; c2.wtype = hd_.enc_c2[i].wtype; c2.bias = hd_.enc_c2_b[i];
-        c2.M = T; c2.N = c; c2.K = c / 2; c2.R = xraw.f(); c2.ldr = c; c2.C = ye.f() + static_cast<size_t>(r) * c; c2.ldc = c; c2.c_act = ACT_ELU;
+        c2.A = h1; c2.lda = c / 2; c2.W = hd_.enc_c2[i].p; c2.wtype = hd_.enc_c2[i].wtype; c2.bias = hd_.enc_c2_b[i];
+        c2.M = T; c2.N = c; c2.K = c / 2; c2.R = xraw; c2.ldr = c; c2.C = ye + static_cast<size_t>(r) * c; c2.ldc = c; c2.c_act = ACT_ELU;
         launch_gemm(c2, stream_);
         const int pn = i < 2 ? rk - 1 : lk - 1;
-        DevBuf xraw2(static_cast<size_t>(To) * 2 * c * 4);
-        DevBuf xe2 = zeros(static_cast<size_t>(pn + To) * 2 * c);
+        float* xraw2 = take(static_cast<size_t>(To) * 2 * c);
+        float* xe2 = take(static_cast<size_t>(pn + To) * 2 * c);
+        PTTS_HIP(hipMemsetAsync(xe2, 0, static_cast<size_t>(pn) * 2 * c * 4, stream_));
         GemmArgs dn;
-        dn.A = ye.f(); dn.lda = r * c; dn.W = hd_.enc_down[i].p; dn.wtype = hd_.enc_down[i].wtype; dn.bias = hd_.enc_down_b[i];
-        dn.M = To; dn.N = 2 * c; dn.K = 2 * r * c; dn.C = xraw2.f(); dn.ldc = 2 * c;
-        dn.C2 = xe2.f() + static_cast<size_t>(pn) * 2 * c; dn.ldc2 = 2 * c; dn.c2_act = ACT_ELU;
+        dn.A = ye; dn.lda = r * c; dn.W = hd_.enc_down[i].p; dn.wtype = hd_.enc_down[i].wtype; dn.bias = hd_.enc_down_b[i];
+        dn.M = To; dn.N = 2 * c; dn.K = 2 * r * c; dn.C = xraw2; dn.ldc = 2 * c;
+        dn.C2 = xe2 + static_cast<size_t>(pn) * 2 * c; dn.ldc2 = 2 * c; dn.c2_act = ACT_ELU;
         launch_gemm(dn, stream_);
-        PTTS_HIP(hipStreamSynchronize(stream_));  // buffers of this stage are released below
-        xraw = std::move(xraw2);
-        xe = std::move(xe2);
+        xraw = xraw2;
+        xe = xe2;
         T = To; c *= 2;
     }
-    DevBuf y(static_cast<size_t>(T) * M * 4);
+    float* y = take(static_cast<size_t>(T) * M);
     GemmArgs fin;
-    fin.A = xe.f(); fin.lda = c; fin.W = hd_.enc_final.p; fin.wtype = hd_.enc_final.wtype; fin.bias = hd_.enc_final_b;
-    fin.M = T; fin.N = M; fin.K = lk * c; fin.C = y.f(); fin.ldc = M;
+    fin.A = xe; fin.lda = c; fin.W = hd_.enc_final.p; fin.wtype = hd_.enc_final.wtype; fin.bias = hd_.enc_final_b;
+    fin.M = T; fin.N = M; fin.K = lk * c; fin.C = y; fin.ldc = M;
     launch_gemm(fin, stream_);
     // transformer over the whole clip from position 0
-    if (T > 16000) throw std::runtime_error("voice clip too long for the encoder attention buffer");
     const int Nv = (T + U - 1) / U, Tpad = Nv * U;
-    DevBuf kc(static_cast<size_t>(s.mimi_layers) * T * M * 4), vc(static_cast<size_t>(s.mimi_layers) * T * M * 4);
-    DevBuf pos = zeros(1);
-    DevBuf sh(static_cast<size_t>(T) * M * 4), sqkv(static_cast<size_t>(T) * 3 * M * 4), sq(static_cast<size_t>(T) * M * 4),
-        satt(static_cast<size_t>(T) * M * 4), sff(static_cast<size_t>(T) * s.mimi_ffn * 4);
-    TfScratch sc{sh.f(), sqkv.f(), sq.f(), satt.f(), sff.f()};
-    DevBuf yd = zeros(static_cast<size_t>(U + Tpad) * M);
-    if (T > model_->mimi_tab_len) throw std::runtime_error("voice clip exceeds the rotary table");
-    transformer(hd_.enc, kc.p, vc.p, 0, static_cast<long long>(T) * M, T, pos.as<int>(), 0, 1, T, y.f(), M, s.mimi_heads, s.mimi_ffn,
+    const size_t TM = static_cast<size_t>(T) * M;
+    float* kc = take(static_cast<size_t>(s.mimi_layers) * TM);
+    float* vc = take(static_cast<size_t>(s.mimi_layers) * TM);
+    int* pos = reinterpret_cast<int*>(take(1, true));
+    float* sh = take(TM); float* sq = take(TM); float* satt = take(TM);
+    float* sqkv = take(3 * TM);
+    float* sff = take(static_cast<size_t>(T) * s.mimi_ffn);
+    TfScratch sc{sh, sqkv, sq, satt, sff};
+    float* yd = take(static_cast<size_t>(U + Tpad) * M);
+    PTTS_HIP(hipMemsetAsync(yd, 0, static_cast<size_t>(U) * M * 4, stream_));
+    if (Tpad > T) PTTS_HIP(hipMemsetAsync(yd + static_cast<size_t>(U + T) * M, 0, static_cast<size_t>(Tpad - T) * M * 4, stream_));
+    transformer(hd_.enc, kc, vc, 0, static_cast<long long>(T) * M, T, pos, 0, 1, T, y, M, s.mimi_heads, s.mimi_ffn,
                 s.mimi_eps, s.mimi_context, model_->mimi_cos, model_->mimi_sin, model_->mimi_tab_len, sc,
-                yd.f() + static_cast<size_t>(U) * M, 0, M, stream_);
-    DevBuf d(static_cast<size_t>(Nv) * M * 4), o(static_cast<size_t>(Nv) * D * 4);
-    GemmArgs ds;
-    ds.A = yd.f(); ds.lda = U * M; ds.W = hd_.enc_ds.p; ds.wtype = hd_.enc_ds.wtype; ds.M = Nv; ds.N = M; ds.K = 2 * U * M; ds.C = d.f(); ds.ldc = M;
-    launch_gemm(ds, stream_);
+                yd + static_cast<size_t>(U) * M, 0, M, stream_);
+    float* d2 = take(static_cast<size_t>(Nv) * M);
+    float* o = take(static_cast<size_t>(Nv) * D);
+    float* slabs = take(static_cast<size_t>(ds_splits) * Nv * M);
+    const int dsK = 2 * U * M;
+    if (model_->enc_ds_packed && Nv <= 128 && M <= 1024 && dsK % (ds_splits * 16) == 0 && !std::getenv("POCKET_TTS_NO_SKINNY_ENCODER")) {
+        // Nv rows against a K of 2 * U * M: eight workgroups as a tiled GEMM; as K-slices on the skinny kernel the
+        // product fills the chip, and the add & norm kernel sums the slices
+        SkinnyArgs k;
+        k.A = yd; k.lda = U * M; k.Wp = model_->enc_ds_packed; k.wtype = W_F32; k.M = Nv; k.N = M; k.K = dsK; k.splits = ds_splits; k.P = slabs;
+        launch_skinny_gemm(k, stream_);
+        PTTS_HIP(hipMemsetAsync(d2, 0, static_cast<size_t>(Nv) * M * 4, stream_));
+        AddNormArgs an;
+        an.X = d2; an.ldx = M; an.M = Nv; an.D = M; an.P = slabs; an.splits = ds_splits;
+        launch_add_norm(an, stream_);
+    } else {
+        GemmArgs ds;
+        ds.A = yd; ds.lda = U * M; ds.W = hd_.enc_ds.p; ds.wtype = hd_.enc_ds.wtype; ds.M = Nv; ds.N = M; ds.K = dsK; ds.C = d2; ds.ldc = M;
+        launch_gemm(ds, stream_);
+    }
     GemmArgs sp;
-    sp.A = d.f(); sp.lda = M; sp.W = hd_.enc_spk.p; sp.wtype = hd_.enc_spk.wtype; sp.M = Nv; sp.N = D; sp.K = M; sp.C = o.f(); sp.ldc = D;
+    sp.A = d2; sp.lda = M; sp.W = hd_.enc_spk.p; sp.wtype = hd_.enc_spk.wtype; sp.M = Nv; sp.N = D; sp.K = M; sp.C = o; sp.ldc = D;
     launch_gemm(sp, stream_);
     std::vector<float> out(static_cast<size_t>(Nv) * D);
-    PTTS_HIP(hipMemcpyAsync(out.data(), o.p, out.size() * 4, hipMemcpyDeviceToHost, stream_));
+    PTTS_HIP(hipMemcpyAsync(out.data(), o, out.size() * 4, hipMemcpyDeviceToHost, stream_));
     PTTS_HIP(hipStreamSynchronize(stream_));
     return out;
 }
