@@ -156,6 +156,25 @@ def test_int8_product_is_exact(full):
     eng.close()
 
 
+def test_full_voice_encoder_parity(full):
+    """Mimi encoder at full size on a 0.5 s and a 1 s clip (the second spans more than one output row group and uses the
+    K-slice down-sampling product): conditioning rows against the oracle, fp32 bound."""
+    eng = full["lib"].Engine(full["path"], precision="fp32", temperature=0.0, lsd_steps=10, max_frames=F)
+    rng = np.random.default_rng(9)
+    worst = 0.0
+    for n in (12000, 24000 + 700):
+        t = np.arange(n) / 24000.0
+        clip = (0.3 * np.sin(2 * np.pi * 180.0 * t) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+        got = eng.mimi_encode(clip)
+        want = full["o"].mimi_encode(clip)
+        assert got.shape == want.shape
+        scale = float(np.abs(want).max())
+        worst = max(worst, float(np.abs(got - want).max()) / max(scale, 1.0))
+    _note(f"fp32 full size voice encoder: max-abs error relative to the largest output {worst:.3e}")
+    assert worst <= 1e-3
+    eng.close()
+
+
 def test_full_streaming_first_chunk(full):
     eng = full["lib"].Engine(full["path"], precision="fp32", temperature=0.0, lsd_steps=10, max_frames=10)
     total, chunks, t_first = eng.streaming_ids(full["ids"][0], full["voices"][0], chunk_frames=5)
