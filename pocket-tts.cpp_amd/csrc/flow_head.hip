@@ -68,10 +68,19 @@ __device__ __forceinline__ float wsum(float v) {
 }
 
 // acc += A[16][k0 .. k0+kstep) * fragment, A in LDS (plane 0 = value or hi term, plane 1 = lo term)
-template <typename WT>
+// ONE (f32 weights, a row group whose only live row is row 0): no matrix instruction.  Each lane multiplies its four
+// weights with row 0's four activations and keeps the sum in acc[0]; one_row_finish() then adds the four k-groups
+// (lanes l, l+16, l+32, l+48), which leaves row 0's value where the MFMA would have put it (lanes 0..15, element 0).
+// A 16x16x4 f32 MFMA takes 32 cycles whatever the number of live rows, and 64 of them per wave were the longest
+// part of a single-utterance launch.
+template <typename WT, bool ONE = false>
 __device__ __forceinline__ void mma_frag(const WT* A0, const WT* A1, int lda, int k0, const uint4 w, f32x4& acc, int lane) {
     const int r = lane & 15, g4 = lane >> 4;
-    if constexpr (std::is_same<WT, float>::value) {
+    if constexpr (ONE) {
+        static_assert(std::is_same<WT, float>::value, "flow head: the one-row form exists for f32 weights only");
+        const float4 a4 = *(const float4*)(A0 + k0 + 4 * g4);
+        acc[0] += (a4.x * __uint_as_float(w.x) + a4.y * __uint_as_float(w.y)) + (a4.z * __uint_as_float(w.z) + a4.w * __uint_as_float(w.w));
+    } else if constexpr (std::is_same<WT, float>::value) {
         const float4 a4 = *(const float4*)(A0 + r * lda + k0 + 4 * g4);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, __uint_as_float(w.x), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, __uint_as_float(w.y), acc, 0, 0, 0);
@@ -83,6 +92,16 @@ __device__ __forceinline__ void mma_frag(const WT* A0, const WT* A1, int lda, in
         const bf16x8 b8 = __builtin_bit_cast(bf16x8, w);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, b8, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, b8, acc, 0, 0, 0);
+    }
+}
+
+template <bool ONE>
+__device__ __forceinline__ void one_row_finish(f32x4& acc) {
+    if constexpr (ONE) {
+        float v = acc[0];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        acc[0] = v;
     }
 }
 
@@ -275,7 +294,7 @@ struct FlowBlockArgs {
 
 // C = flow_dim, G = column/K split, L = latent_dim; PF: request every weight fragment of the launch up front
 // (needs (C/16/G/8 * C/kstep + C/16/8 * C/kstep/G) * 4 VGPRs, so only for bf16 at C <= 512).
-template <typename WT, int C, int G, int L, bool PF, int RPW, bool FIN = false>
+template <typename WT, int C, int G, int L, bool PF, int RPW, bool FIN = false, bool ONE = false>
 __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using T = FlowTraits<WT>;
@@ -291,6 +310,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
     static_assert(NT % G == 0 && KS % G == 0 && L % KSTEP == 0, "flow head: split does not tile");
     static_assert(kFlowWaves % KP1 == 0 && KS % KP1 == 0 && (size_t)kFlowWaves * T1 * 256 <= (size_t)16 * C, "flow head: fc1 K split over waves does not tile");
     static_assert(RPW * kFlowWaves >= 16 || RPW == 1, "flow head: rows per wave");
+    static_assert(!(FIN && ONE), "flow head: the one-row form has no fused tail");
     float* hbuf = (float*)smem_raw;                         // [16][C]   (first block only)
     WT* A0 = (WT*)(hbuf + 16 * C);                          // [PL][16][lda]
     WT* A1 = A0 + (PL - 1) * 16 * lda;
@@ -419,7 +439,8 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
             const int t = wave + kFlowWaves * i;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KSL; ++ks) mma_frag<WT>(X0, X1, ldx, ks * KSTEP, wi[i][ks], acc, lane);
+            for (int ks = 0; ks < KSL; ++ks) mma_frag<WT, ONE>(X0, X1, ldx, ks * KSTEP, wi[i][ks], acc, lane);
+            one_row_finish<ONE>(acc);
             if (t < NT) {
                 const int c = t * 16 + ccol;
 #pragma unroll
@@ -476,7 +497,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
             uint4 w;
             if constexpr (PF) w = wf1[i][ks];
             else w = w1p[((long long)tc * KS + kp1 * KSW + ks) * 64];
-            mma_frag<WT>(A0, A1, lda, (kp1 * KSW + ks) * KSTEP, w, acc1[i], lane);
+            mma_frag<WT, ONE>(A0, A1, lda, (kp1 * KSW + ks) * KSTEP, w, acc1[i], lane);
         }
     }
     if (kp1 > 0) {
@@ -494,6 +515,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
                 const f32x4 o = *(const f32x4*)(red + ((k * WPP + wave) * T1 + i) * 256 + lane * 4);
                 acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3];
             }
+            one_row_finish<ONE>(acc);
             if (t < NT1) {
                 const int cl = t * 16 + ccol;
 #pragma unroll
@@ -517,8 +539,9 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
             uint4 w;
             if constexpr (PF) w = wf2[i][ks];
             else w = w2p[((long long)tc * KS + ks) * 64];
-            mma_frag<WT>(S0, S1, lda2, ks * KSTEP, w, acc, lane);
+            mma_frag<WT, ONE>(S0, S1, lda2, ks * KSTEP, w, acc, lane);
         }
+        one_row_finish<ONE>(acc);
         if (t < NT) {
             const int c = t * 16 + ccol;
 #pragma unroll
@@ -755,7 +778,7 @@ struct FlowFinalArgs {
 
 // Last residual update, final adaLN, output projection (K split over the waves, summed through LDS in wave
 // order), x_out = x_in + dt * v.
-template <typename WT, int C, int G, int L, int RPW>
+template <typename WT, int C, int G, int L, int RPW, bool ONE = false>
 __global__ __launch_bounds__(kFlowThreads) void flow_final_kernel(FlowFinalArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using T = FlowTraits<WT>;
@@ -794,7 +817,8 @@ __global__ __launch_bounds__(kFlowThreads) void flow_final_kernel(FlowFinalArgs 
     __syncthreads();
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < KSP; ++ks) mma_frag<WT>(A0, A1, lda, (kp * KSP + ks) * KSTEP, wo[ks], acc, lane);
+    for (int ks = 0; ks < KSP; ++ks) mma_frag<WT, ONE>(A0, A1, lda, (kp * KSP + ks) * KSTEP, wo[ks], acc, lane);
+    one_row_finish<ONE>(acc);
     *(f32x4*)(red + wave * 256 + lane * 4) = acc;
     __syncthreads();
     const float* xin = a.x_in + (a.x_step ? (long long)(*a.x_step + a.x_step_bias) * a.x_step_stride : 0);
@@ -848,7 +872,7 @@ constexpr int kMaxFlowSplit = 8;
 static void flow_head_shape(int C, int B, bool bf, int& G, int& rpg) {
     G = 4; rpg = 16;
     if (bf && C == 512 && B > 4) rpg = 4;   // measured at B = 64: 4 x 16 -> 627 us per chain, 4 x 4 -> 578 us, 8 x any -> 670+ us
-    if (!bf && C == 512 && B <= 8) G = 8;   // a streaming call's single row: 877 us per chain with 4 slices of float weights, 664 us with 8
+    if (!bf && C == 512 && B <= 8) G = 8;   // a streaming call's single row: 877 us per chain with 4 slices of float weights, 375 us with 8 and no MFMA
     if (const char* e = std::getenv("FLOW_HEAD_SPLIT")) G = std::atoi(e) == 8 && C == 512 ? 8 : 4;
     if (const char* e = std::getenv("FLOW_HEAD_ROWS")) { const int r = std::atoi(e); if (r == 1 || r == 2 || r == 4 || r == 8 || r == 16) rpg = r; }
 }
@@ -871,16 +895,17 @@ static void set_lds_limit(const void* kernel, size_t smem) {
 }
 
 // FUSE: the tail of Euler step j-1 runs inside the first block launch of step j (one launch less per step)
-template <typename WT, int C, bool PF, int G = 4, int RPW = 2, bool FUSE = false>
+template <typename WT, int C, bool PF, int G = 4, int RPW = 2, bool FUSE = false, bool ONE = false>
 static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
     constexpr int L = 32;
     using T = FlowTraits<WT>;
     const int B = a.B, RG = (B + rpg - 1) / rpg;
     const size_t smem_block = (size_t)16 * C * 4 + (size_t)T::planes * 16 * ((C + T::pad) + (C / G + T::pad) + (L + T::pad)) * sizeof(WT);
     const size_t smem_final = (size_t)T::planes * 16 * (C + T::pad) * sizeof(WT) + (size_t)kFlowWaves * 256 * 4;
-    auto kb = flow_block_kernel<WT, C, G, L, PF, RPW>;
-    auto kbf = flow_block_kernel<WT, C, G, L, PF, RPW, FUSE>;
-    auto kf = flow_final_kernel<WT, C, G, L, RPW>;
+    auto kb = flow_block_kernel<WT, C, G, L, PF, RPW, false, ONE>;
+    auto kbf = flow_block_kernel<WT, C, G, L, PF, RPW, FUSE, ONE>;
+    auto kf = flow_final_kernel<WT, C, G, L, RPW, ONE>;
+    if (ONE && a.B != 1) throw std::runtime_error("flow head: the one-row form serves a single row");
     if (rpg > RPW * kFlowWaves) throw std::runtime_error("flow head: row group larger than the waves can cover");
     set_lds_limit((const void*)kb, smem_block);
     set_lds_limit((const void*)kbf, smem_block);
@@ -967,7 +992,11 @@ void flow_head_prepare(int C, int wtype) {
                 prepare_chain<__bf16, 512, true>(); prepare_chain<__bf16, 512, true, 4, 1>(); prepare_chain<__bf16, 512, true, 8, 1>();
                 set_lds_limit((const void*)flow_block_kernel<__bf16, 512, 4, 32, true, 1, true>, 128 * 1024);
             }
-            else { prepare_chain<float, 512, false>(); prepare_chain<float, 512, false, 8>(); }
+            else {
+                prepare_chain<float, 512, false>(); prepare_chain<float, 512, false, 8, 1>();
+                set_lds_limit((const void*)flow_block_kernel<float, 512, 8, 32, false, 1, false, true>, 128 * 1024);
+                set_lds_limit((const void*)flow_final_kernel<float, 512, 8, 32, 1, true>, 128 * 1024);
+            }
             break;
         case 1024: bf ? prepare_chain<__bf16, 1024, false>() : prepare_chain<float, 1024, false>(); break;
         default: throw std::runtime_error("flow head: flow_dim must be 128, 256, 512 or 1024");
@@ -1001,7 +1030,8 @@ void launch_flow_head(const FlowHeadArgs& a, hipStream_t s) {
             else if (bf && rpg <= 8 && !std::getenv("FLOW_HEAD_NO_FUSE")) run_chain<__bf16, 512, true, 4, 1, true>(a, s, rpg);
             else if (bf && rpg <= 8) run_chain<__bf16, 512, true, 4, 1>(a, s, rpg);
             else if (bf) run_chain<__bf16, 512, true>(a, s, rpg);
-            else if (!bf && G == 8) run_chain<float, 512, false, 8>(a, s, rpg);
+            else if (!bf && G == 8 && a.B == 1 && !std::getenv("FLOW_HEAD_NO_ONE_ROW")) run_chain<float, 512, false, 8, 1, false, true>(a, s, 4);
+            else if (!bf && G == 8) run_chain<float, 512, false, 8, 1>(a, s, 8);   // one row per wave: two would spill (8 partials per row)
             else run_chain<float, 512, false>(a, s, rpg);
             break;
         case 1024: bf ? run_chain<__bf16, 1024, false>(a, s, rpg) : run_chain<float, 1024, false>(a, s, rpg); break;

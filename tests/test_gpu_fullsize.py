@@ -156,6 +156,26 @@ def test_int8_product_is_exact(full):
     eng.close()
 
 
+def test_full_fp32_single_utterance_parity(full):
+    """One utterance alone takes the single-row forms of the kernels (float flow head without matrix instructions,
+    8 slices; prefill on the skinny kernels): flow head and whole path against the oracle, fp32 bound."""
+    eng = full["lib"].Engine(full["path"], precision="fp32", temperature=0.0, lsd_steps=10, max_frames=F)
+    rng = np.random.default_rng(21)
+    cond = rng.standard_normal((1, full["spec"].d_model)).astype(np.float32)
+    x0 = (rng.standard_normal((1, full["spec"].latent_dim)) * 0.8).astype(np.float32)
+    got = eng.flow_euler(cond, x0)[0]
+    want = full["o"].flow_euler(cond[0], x0[0], 10)
+    flow_err = float(np.abs(got - want).max())
+    res = eng.generate_ids(full["ids"][:1], full["voices"][:1])[0]
+    lat, eos, frames = oracle_replay(full["o"], full["ids"][0], full["voices"][0], res["latents"], 10, F)
+    assert res["frames"] == frames == F
+    worst = max(float(np.abs(res["latents"] - lat).max()), float(np.abs(res["eos"] - eos).max()))
+    snr = snr_db(oracle_decode(full["o"], res["latents"]), res["audio"])
+    _note(f"fp32 full size, one utterance: flow head max-abs {flow_err:.3e}, per-frame latent/eos max-abs {worst:.3e}, PCM SNR {snr:.1f} dB")
+    assert flow_err <= 1e-3 and worst <= 1e-3 and snr >= 40.0
+    eng.close()
+
+
 def test_full_voice_encoder_parity(full):
     """Mimi encoder at full size on a 0.5 s and a 1 s clip (the second spans more than one output row group and uses the
     K-slice down-sampling product): conditioning rows against the oracle, fp32 bound."""
