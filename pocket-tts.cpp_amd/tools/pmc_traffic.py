@@ -19,7 +19,9 @@ def per_kernel(path, counter):
         for row in csv.DictReader(f):
             if row.get("Counter_Name") != counter:
                 continue
-            name = row["Kernel_Name"].split("(")[0]
+            name = row["Kernel_Name"]
+            if name.endswith(")") and "(" in name:
+                name = name[:name.rindex("(")]      # drop the argument list, keep "(anonymous namespace)"
             tot[name] += float(row["Counter_Value"])
             cnt[name] += 1
     return {k: (tot[k] / cnt[k] * 1024.0, cnt[k]) for k in tot}
