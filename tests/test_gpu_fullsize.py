@@ -80,6 +80,47 @@ def test_full_bf16_offline_parity(full):
     eng.close()
 
 
+def test_full_batch64_bench_shape(full):
+    """The bench shape (64 utterances, 32 ids, 62 voice rows, bf16) for 6 frames: (1) two runs are bit-identical,
+    (2) utterances 0, 17 and 63 replayed by the oracle on the same bf16-rounded weights stay inside the bf16 bound,
+    (3) an utterance generated alone (other kernel variants: one row per row group) gives the same first frame to
+    the bf16 bound, (4) ragged lengths: a batch whose utterances differ in text and voice length matches the same
+    utterances generated in a uniform batch of their own."""
+    spec = full["spec"]
+    Fb = 6
+    eng = full["lib"].Engine(full["path"], precision="bf16", temperature=0.0, lsd_steps=10, max_frames=Fb)
+    ids, voices = [], []
+    for i in range(64):
+        r = np.random.default_rng(500 + i)
+        ids.append(r.integers(0, spec.vocab, 32).astype(np.int64))
+        voices.append((r.standard_normal((62, spec.d_model)) * 0.5).astype(np.float32))
+    a = eng.generate_ids(ids, voices, want_audio=False)
+    b = eng.generate_ids(ids, voices, want_audio=False)
+    for i in range(64):
+        assert a[i]["frames"] == Fb
+        np.testing.assert_array_equal(a[i]["latents"], b[i]["latents"])
+    worst = 0.0
+    for i in (0, 17, 63):
+        lat, _, frames = oracle_replay(full["oq"], ids[i], voices[i], a[i]["latents"], 10, Fb)
+        assert frames == Fb
+        worst = max(worst, float(np.abs(a[i]["latents"] - lat).max()))
+    alone = eng.generate_ids(ids[17:18], voices[17:18], want_audio=False)[0]
+    first = float(np.abs(alone["latents"][0] - a[17]["latents"][0]).max())
+    # ragged batch: utterance k keeps 8 + k % 25 ids and 20 + (7 k) % 43 voice rows
+    rid = [ids[k][: 8 + k % 25] for k in range(64)]
+    rvo = [voices[k][: 20 + (7 * k) % 43] for k in range(64)]
+    rag = eng.generate_ids(rid, rvo, want_audio=False)
+    worst_r = 0.0
+    for k in (3, 40, 62):
+        lat, _, frames = oracle_replay(full["oq"], rid[k], rvo[k], rag[k]["latents"], 10, Fb)
+        assert frames == Fb
+        worst_r = max(worst_r, float(np.abs(rag[k]["latents"] - lat).max()))
+    _note(f"bf16 full size, 64 utterances: per-frame latent max-abs vs oracle(bf16 weights) {worst:.3e}, ragged batch {worst_r:.3e}, "
+          f"first frame alone vs in the batch {first:.3e}")
+    assert worst <= 2e-2 and worst_r <= 2e-2 and first <= 2e-2
+    eng.close()
+
+
 def test_full_int8_graphs_and_offline_parity(full):
     """int8 engine (int8 LM-layer and flow-block matrices on v_mfma_i32, block-quantised activations) against the
     oracle running the same quantisation scheme on the same weights: graph by graph, then per frame."""
