@@ -253,8 +253,9 @@ __global__ __launch_bounds__(256) void skinny_q8_kernel(SkinnyArgs a) {
                 const i32x4 z = {0, 0, 0, 0};
                 const i32x4 ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a4, b4, z, 0, 0, 0);
                 const float4 d4 = *(const float4*)(&Dq[c & 1][ks][mt * 16 + 4 * g]);
-                acc[mt][0] += (float)ci[0] * d4.x; acc[mt][1] += (float)ci[1] * d4.y;
-                acc[mt][2] += (float)ci[2] * d4.z; acc[mt][3] += (float)ci[3] * d4.w;
+                // explicit fused multiply-adds: both int8 product kernels must round alike whatever the compiler pairs up
+                acc[mt][0] = __builtin_fmaf((float)ci[0], d4.x, acc[mt][0]); acc[mt][1] = __builtin_fmaf((float)ci[1], d4.y, acc[mt][1]);
+                acc[mt][2] = __builtin_fmaf((float)ci[2], d4.z, acc[mt][2]); acc[mt][3] = __builtin_fmaf((float)ci[3], d4.w, acc[mt][3]);
             }
         }
     }
@@ -267,13 +268,109 @@ __global__ __launch_bounds__(256) void skinny_q8_kernel(SkinnyArgs a) {
         for (int i = 0; i < 4; ++i) {
             const int row = m0 + mt * 16 + g * 4 + i;
             if (row >= a.M) continue;
-            float v = acc[mt][i] * ws;
+            float v = __fmul_rn(acc[mt][i], ws);
             if (a.P) {
                 a.P[((long long)blockIdx.y * a.M + row) * a.N + col] = v;
             } else {
-                if (a.bias) v += a.bias[col];
+                if (a.bias) v = __fadd_rn(v, a.bias[col]);
                 a.C[(long long)row * a.ldc + col] = act_dev(v, a.act);
             }
+        }
+    }
+}
+
+// The same product with activations that arrive quantised (SkinnyArgs::Aq / Ad): nothing is staged.  A wave's A
+// fragment of k-step ks is 16 bytes per lane straight from the int8 rows (lane (r, g): row m0 + r, k = 64 ks + 16 g ..),
+// its scales one float4 of Ad[ks][m0 + 4 g ..]; with the weight fragment that is three independent loads per k-step and no
+// LDS, no barrier.  Four k-steps are in flight while the previous four are multiplied.  16 rows per workgroup.
+__global__ __launch_bounds__(256) void skinny_q8p_kernel(SkinnyArgs a) {
+    __shared__ float smax[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x * 4 + wave;
+    const bool tile_live = nt * 16 < a.N;
+    const int ntc = tile_live ? nt : 0;
+    const int m0 = blockIdx.z * 16;
+    const int nks = a.K / a.splits / 64, ks0 = blockIdx.y * nks, KS_total = a.K / 64;
+    const int r = lane & 15, g = lane >> 4;
+    const bool row_ok = m0 + r < a.M;
+    const uint4* wp = (const uint4*)a.Wp + ((long long)ntc * KS_total + ks0) * 64 + lane;
+    const signed char* ap = a.Aq + (long long)(row_ok ? m0 + r : 0) * a.ldaq + (long long)ks0 * 64 + 16 * g;
+    const float* dp = a.Ad + (long long)ks0 * a.Mq + m0 + 4 * g;
+    uint4 an[4], bn[4];
+    float4 dn[4];
+    auto request = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ks = c + i < nks ? c + i : nks - 1;   // past the end: a repeat of the last step, not used
+            an[i] = *(const uint4*)(ap + (long long)ks * 64);
+            bn[i] = wp[(long long)ks * 64];
+            dn[i] = *(const float4*)(dp + (long long)ks * a.Mq);
+        }
+    };
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    request(0);
+    for (int c = 0; c < nks; c += 4) {
+        uint4 ac[4], bc[4];
+        float4 dc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ac[i] = an[i]; bc[i] = bn[i]; dc[i] = dn[i]; }
+        if (c + 4 < nks) request(c + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (c + i >= nks) break;
+            const i32x4 z = {0, 0, 0, 0};
+            const i32x4 a4 = row_ok ? __builtin_bit_cast(i32x4, ac[i]) : z;
+            const i32x4 ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a4, __builtin_bit_cast(i32x4, bc[i]), z, 0, 0, 0);
+            acc[0] = __builtin_fmaf((float)ci[0], dc[i].x, acc[0]); acc[1] = __builtin_fmaf((float)ci[1], dc[i].y, acc[1]);
+            acc[2] = __builtin_fmaf((float)ci[2], dc[i].z, acc[2]); acc[3] = __builtin_fmaf((float)ci[3], dc[i].w, acc[3]);
+        }
+    }
+    const int col = ntc * 16 + r;
+    const float ws = a.wscale[col];
+    if (a.Cq) {
+        // result as int8 blocks of 64 columns = this workgroup's four tiles: row maxima over a tile's 16 columns by DPP
+        // (the 16 lanes of one g), over the four waves through LDS
+        const float bias = a.bias ? a.bias[col] : 0.f;
+        float v[4], mx[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = __fmul_rn(acc[i], ws);
+            if (a.bias) t = __fadd_rn(t, bias);      // the same two roundings as the f32 epilogues
+            v[i] = act_dev(t, a.act);
+            float m = fabsf(v[i]);
+            m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, true)));
+            m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, true)));
+            m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x141, 0xF, 0xF, true)));
+            m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x140, 0xF, 0xF, true)));
+            mx[i] = m;
+        }
+        if (r == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) smax[wave][4 * g + i] = mx[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = 4 * g + i, row = m0 + rr;
+            const float m = fmaxf(fmaxf(smax[0][rr], smax[1][rr]), fmaxf(smax[2][rr], smax[3][rr]));
+            if (row >= a.M) continue;
+            const float inv = m > 0.f ? 127.0f / m : 0.f;
+            a.Cq[(long long)row * a.N + col] = (signed char)(int)rintf(v[i] * inv);
+            if (wave == 0 && r == 0) a.Cd[(long long)blockIdx.x * a.Mq + row] = m / 127.0f;
+        }
+        return;
+    }
+    if (!tile_live) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + g * 4 + i;
+        if (row >= a.M) continue;
+        float v = __fmul_rn(acc[i], ws);
+        if (a.P) {
+            a.P[((long long)blockIdx.y * a.M + row) * a.N + col] = v;
+        } else {
+            if (a.bias) v = __fadd_rn(v, a.bias[col]);
+            a.C[(long long)row * a.ldc + col] = act_dev(v, a.act);
         }
     }
 }
@@ -310,7 +407,7 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
     const bool bf = a.wtype == W_BF16;
     const int kstep = a.wtype == W_I8 ? 64 : bf ? 32 : 16;
     if (a.wtype == W_I8 && !a.wscale) throw std::runtime_error("skinny gemm: int8 weights need their scales");
-    if (a.N % 16 || a.K % kstep || a.splits <= 0 || a.K % a.splits || (a.K / a.splits) % kstep || (a.lda % 4) || ((uintptr_t)a.A & 15))
+    if (a.N % 16 || a.K % kstep || a.splits <= 0 || a.K % a.splits || (a.K / a.splits) % kstep || (!a.Aq && ((a.lda % 4) || ((uintptr_t)a.A & 15))))
         throw std::runtime_error("skinny gemm: shape not tileable (N % 16, K % k-step, K % splits, lda alignment)");
     if (!a.P && a.splits != 1) throw std::runtime_error("skinny gemm: split K needs a partial buffer");
     dim3 grid((a.N + 63) / 64, a.splits, (a.M + 63) / 64), block(256);
@@ -327,6 +424,15 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
         while (mt > 1 && cols * ((a.M + 16 * mt - 1) / (16 * mt)) < 512) mt >>= 1;
         if (a.M <= 16 * (mt / 2)) mt = a.M <= 16 ? 1 : 2;     // never stage rows that do not exist
     }
+    if (a.Aq) {
+        if (a.wtype != W_I8 || !a.Ad || a.Mq < ((a.M + 15) & ~15) || (a.Mq & 3) || (a.ldaq & 15) || ((uintptr_t)a.Aq & 15) || ((uintptr_t)a.Ad & 15))
+            throw std::runtime_error("skinny gemm: quantised activations need int8 weights, scales [K/64][Mq] and 16-byte aligned rows");
+        if (a.Cq && (!a.Cd || a.N % 64 || a.splits != 1)) throw std::runtime_error("skinny gemm: a quantised result needs N % 64 == 0 and no K split");
+        grid.z = (a.M + 15) / 16;
+        hipLaunchKernelGGL(skinny_q8p_kernel, grid, block, 0, s, a);
+        return;
+    }
+    if (a.Cq) throw std::runtime_error("skinny gemm: a quantised result is produced from quantised activations only");
     grid.z = (a.M + 16 * mt - 1) / (16 * mt);
     if (a.wtype == W_I8) {
         if (mt == 1) hipLaunchKernelGGL(skinny_q8_kernel<1>, grid, block, 0, s, a);
@@ -444,11 +550,22 @@ __global__ __launch_bounds__(256) void add_norm_kernel(AddNormArgs a) {
     const float d0 = on ? v.x - mean : 0.f, d1 = on ? v.y - mean : 0.f, d2 = on ? v.z - mean : 0.f, d3 = on ? v.w - mean : 0.f;
     const float rstd = 1.0f / sqrtf(block_sum4((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3), red, tid) / (float)a.D + a.eps);
     float dot = 0.f;
+    // (computed once: the int8 form below must round the very values the f32 form stores)
+    const float y0 = d0 * rstd * g4.x + b4.x, y1 = d1 * rstd * g4.y + b4.y, y2 = d2 * rstd * g4.z + b4.z, y3 = d3 * rstd * g4.w + b4.w;
     if (on) {
-        const float y0 = d0 * rstd * g4.x + b4.x, y1 = d1 * rstd * g4.y + b4.y, y2 = d2 * rstd * g4.z + b4.z, y3 = d3 * rstd * g4.w + b4.w;
         if (a.H) *(float4*)(a.H + (long long)m * a.D + c) = make_float4(y0, y1, y2, y3);
         if (a.H32) *(float4*)(a.H32 + (long long)m * a.D + c) = make_float4(y0, y1, y2, y3);
         dot = (y0 * w4.x + y1 * w4.y) + (y2 * w4.z + y3 * w4.w);
+    }
+    if (a.Hq) {
+        // y as int8: a block of 64 channels is 16 consecutive threads (one DPP row)
+        const float4 y4 = on ? make_float4(y0, y1, y2, y3) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float bm = block_absmax16(y4);
+        const float inv = bm > 0.f ? 127.0f / bm : 0.f;
+        if (on) {
+            *(unsigned*)(a.Hq + (long long)m * a.D + c) = quantize4(y4, inv);
+            if ((tid & 15) == 0) a.Hd[(long long)(c >> 6) * a.Mq + m] = bm / 127.0f;
+        }
     }
     if (a.dot_w) {
         dot = block_sum4(dot, red, tid);
@@ -460,6 +577,7 @@ void launch_add_norm(const AddNormArgs& a, hipStream_t s) {
     if (a.M <= 0) return;
     if (a.D % 4 || a.D > 1024 || (a.ldx & 3)) throw std::runtime_error("add_norm: width must be a multiple of 4 and <= 1024");
     if (a.P && (a.splits < 1 || a.splits > 16)) throw std::runtime_error("add_norm: 1..16 K-slices supported");
+    if (a.Hq && (!a.Hd || a.D % 64 || a.Mq < a.M || !a.g)) throw std::runtime_error("add_norm: int8 output needs scales, D % 64 == 0 and a normalisation");
     if (a.seq && (!a.w_in || a.L <= 0 || (a.L & 7) || a.P)) throw std::runtime_error("add_norm: the projection prologue needs L % 8 == 0 and no K-slices");
     dim3 grid(a.M), block(256);
     if (a.splits <= 8) hipLaunchKernelGGL(add_norm_kernel<8>, grid, block, 0, s, a);
@@ -697,12 +815,22 @@ __global__ __launch_bounds__(256, 4) void attn_decode_kernel(AttnDecodeArgs a) {
         }
     }
     const float out = acc / tot;
-    a.out[(long long)m * a.d + h * 64 + lane] = out;
+    if (a.out_q) {   // a head's 64 channels are one quantisation block of the output product
+        float bm = fabsf(out);
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) bm = fmaxf(bm, __shfl_xor(bm, of, 64));
+        const float inv = bm > 0.f ? 127.0f / bm : 0.f;
+        a.out_q[(long long)m * a.d + h * 64 + lane] = (signed char)(int)rintf(out * inv);
+        if (lane == 0) a.out_d[(long long)h * a.Mq + m] = bm / 127.0f;
+    } else {
+        a.out[(long long)m * a.d + h * 64 + lane] = out;
+    }
 }
 
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     if (a.M <= 0) return;
     if (a.d != a.heads * 64) throw std::runtime_error("attention: head dimension must be 64");
+    if (a.out_q && (!a.out_d || a.Mq < a.M)) throw std::runtime_error("attention: int8 output needs its scale buffer");
     const int scap = std::max((a.cap / 4 + 8) & ~3, 64);
     const size_t smem = ((size_t)4 * (64 + scap) + 16 * 68) * sizeof(float);
     if (smem > 64 * 1024) throw std::runtime_error("attention: context capacity too large for the LDS score buffer");

@@ -378,6 +378,13 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     *h_flag = 0;
     step_dev.alloc(64);
     partial.alloc(static_cast<size_t>(16) * B * D * 4);   // up to 16 K-slice slabs, sized once: the frame graph holds the pointer
+    if (e.model().lm_wtype == W_I8 && D % 64 == 0 && s.lm_ffn % 64 == 0 && D == s.lm_heads * 64) {
+        q_rows = (B + 15) & ~15;
+        auto zeroed = [&](DevBuf& d, size_t bytes) { d.alloc(bytes); PTTS_HIP(hipMemset(d.p, 0, bytes)); };
+        zeroed(hq, static_cast<size_t>(B) * D); zeroed(hd, static_cast<size_t>(D / 64) * q_rows * 4);
+        zeroed(attq, static_cast<size_t>(B) * D); zeroed(attd, static_cast<size_t>(s.lm_heads) * q_rows * 4);
+        zeroed(ffq, static_cast<size_t>(B) * s.lm_ffn); zeroed(ffd, static_cast<size_t>(s.lm_ffn / 64) * q_rows * 4);
+    }
     for (auto& pair : tev)
         for (auto& ev : pair) PTTS_HIP(hipEventCreate(&ev));
     reset(e.stream());
@@ -815,9 +822,13 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
     if (s_qkv < 1 || D % s_qkv || (D / s_qkv) % kstep) s_qkv = 1;
     if (b.qkv.bytes < static_cast<size_t>(s_qkv) * B * 3 * D * 4) throw std::runtime_error("QKV slab buffer too small");
     if (b.partial.bytes < static_cast<size_t>(std::max(s_out, s_ff2)) * B * D * 4) throw std::runtime_error("split-K slab buffer too small");
+    // int8 engine: every matrix input of the step is quantised by the kernel that produces it (add & norm, attention,
+    // the FFN-1 epilogue), so the products read int8 rows and stage nothing
+    const bool preq = wt == W_I8 && b.q_rows > 0 && !std::getenv("POCKET_TTS_Q8_STAGED");
     AddNormArgs an;
     an.X = b.x.f(); an.ldx = D; an.M = B; an.D = D; an.eps = s.lm_eps;
     an.g = hd_.lm[0].ln1g; an.b = hd_.lm[0].ln1b; an.H = b.h.f();
+    if (preq) { an.H = nullptr; an.Hq = b.hq.as<signed char>(); an.Hd = b.hd.f(); an.Mq = b.q_rows; }
     {
         AddNormArgs a0 = an;
         if (proj_in_norm) { a0.seq = seq_rows; a0.w_in = win.p; a0.w_in_type = win.wtype; a0.L = s.latent; }
@@ -830,6 +841,7 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         SkinnyArgs q;
         q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.wtype = wt; q.wscale = pw.s_qkv; q.M = B; q.N = 3 * D; q.K = D;
         q.splits = s_qkv; q.P = b.qkv.f();   // K-slice slabs, summed where the attention kernel reads them
+        if (preq) { q.A = nullptr; q.Aq = b.hq.as<signed char>(); q.ldaq = D; q.Ad = b.hd.f(); q.Mq = b.q_rows; }
         launch_skinny_gemm(q, b.st);
         AttnDecodeArgs at;
         const long long kv_off = static_cast<long long>(l) * layer_stride * (b.kv16 ? 2 : 4);
@@ -837,9 +849,11 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         at.pos = b.lm_pos.as<int>(); at.M = B; at.d = D; at.heads = s.lm_heads; at.cap = b.lm_cap; at.window = 0;
         at.cos_tab = model_->lm_cos; at.sin_tab = model_->lm_sin; at.tab_len = model_->lm_tab_len;
         at.out = b.att.f();
+        if (preq) { at.out = nullptr; at.out_q = b.attq.as<signed char>(); at.out_d = b.attd.f(); at.Mq = b.q_rows; }
         launch_attn_decode(at, b.st);
         SkinnyArgs o;
         o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.wtype = wt; o.wscale = pw.s_out; o.M = B; o.N = D; o.K = D; o.splits = s_out; o.P = b.partial.f();
+        if (preq) { o.A = nullptr; o.Aq = b.attq.as<signed char>(); o.ldaq = D; o.Ad = b.attd.f(); o.Mq = b.q_rows; }
         launch_skinny_gemm(o, b.st);
         AddNormArgs a1 = an;
         a1.P = b.partial.f(); a1.splits = s_out; a1.colscale = w.ls1; a1.g = w.ln2g; a1.b = w.ln2b;
@@ -847,16 +861,21 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         SkinnyArgs f1;
         f1.A = b.h.f(); f1.lda = D; f1.Wp = pw.ff1; f1.wtype = wt; f1.wscale = pw.s_ff1; f1.M = B; f1.N = F; f1.K = D; f1.act = ACT_GELU;
         f1.C = b.ff.f(); f1.ldc = F;
+        if (preq) {
+            f1.A = nullptr; f1.Aq = b.hq.as<signed char>(); f1.ldaq = D; f1.Ad = b.hd.f(); f1.Mq = b.q_rows;
+            f1.C = nullptr; f1.Cq = b.ffq.as<signed char>(); f1.Cd = b.ffd.f();
+        }
         launch_skinny_gemm(f1, b.st);
         SkinnyArgs f2;
         f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.wtype = wt; f2.wscale = pw.s_ff2; f2.M = B; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.partial.f();
+        if (preq) { f2.A = nullptr; f2.Aq = b.ffq.as<signed char>(); f2.ldaq = F; f2.Ad = b.ffd.f(); f2.Mq = b.q_rows; }
         launch_skinny_gemm(f2, b.st);
         AddNormArgs a2 = an;
         a2.P = b.partial.f(); a2.splits = s_ff2; a2.colscale = w.ls2;
         if (l + 1 < s.lm_layers) {
             a2.g = hd_.lm[l + 1].ln1g; a2.b = hd_.lm[l + 1].ln1b;
         } else {
-            a2.g = hd_.out_g; a2.b = hd_.out_b; a2.H32 = cond_dev;
+            a2.g = hd_.out_g; a2.b = hd_.out_b; a2.H32 = cond_dev; a2.Hq = nullptr; a2.H = preq ? nullptr : a2.H;
             a2.dot_w = hd_.eos_w; a2.dot_b = hd_.eos_b; a2.dot_out = eos_dev;
             a2.pos = b.lm_pos.as<int>(); a2.pos_delta = 1;
         }

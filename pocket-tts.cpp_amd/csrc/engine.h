@@ -295,6 +295,8 @@ public:
     // flow scratch
     DevBuf cemb, ymod, mods, flow_ws;
     DevBuf partial;   // split-K slabs of the decode step [splits][B][d_model] f32
+    DevBuf hq, hd, attq, attd, ffq, ffd;   // int8 engine: the decode step's matrix inputs as int8 rows + block scales [K / 64][Mq]
+    int q_rows = 0;                        // Mq = B rounded up to 16
     DevBuf pre_partial;   // K-slice slabs [splits][rows][d_model] of a prefill pass on the skinny kernels
     // audio out
     DevBuf audio;

@@ -171,6 +171,11 @@ struct SkinnyArgs {
     const float* wscale = nullptr;   // W_I8: per-output-column weight scale
     int mtiles = 0;                  // 16-row tiles per workgroup: 1, 2 or 4 (0 = 4)
     int kchunk = 0;                  // K elements staged per step: 128, 256 or 512 (bf16, mtiles <= 2); 0 = 128
+    // W_I8 only, activations quantised by the kernel that produced them (per row and block of 64 k: q = rint(a * 127 / max|a|),
+    // d = max|a| / 127): Aq[M][ldaq] int8 and Ad[K / 64][Mq] f32 replace A; Mq = M rounded up to 16
+    const signed char* Aq = nullptr; int ldaq = 0; const float* Ad = nullptr; int Mq = 0;
+    // ... and the same form of the result instead of C (needs N % 64 == 0): Cq[M][N], Cd[N / 64][Mq]
+    signed char* Cq = nullptr; float* Cd = nullptr;
 };
 void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s);
 
@@ -183,6 +188,7 @@ struct AddNormArgs {
     const float* colscale = nullptr; const float* pbias = nullptr;
     const float* g = nullptr; const float* b = nullptr; float eps = 1e-5f;
     float* H = nullptr; float* H32 = nullptr;
+    signed char* Hq = nullptr; float* Hd = nullptr; int Mq = 0;   // y also (or instead of H) as int8 blocks of 64 + scales [D / 64][Mq]
     const float* dot_w = nullptr; const float* dot_b = nullptr; float* dot_out = nullptr;
     int* pos = nullptr; int pos_delta = 0;
     int M = 0, D = 0;
@@ -202,6 +208,7 @@ struct AttnDecodeArgs {
     int M = 0, d = 0, heads = 0, cap = 0, window = 0;
     const float* cos_tab = nullptr; const float* sin_tab = nullptr; int tab_len = 0;
     float* out = nullptr;
+    signed char* out_q = nullptr; float* out_d = nullptr; int Mq = 0;   // instead of out: int8 per (row, head) + scales [heads][Mq]
 };
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
 

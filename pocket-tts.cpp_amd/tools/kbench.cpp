@@ -104,6 +104,26 @@ static void bench_skinny_q8(const char* name, int M, int N, int K, int splits, i
     time_it(name, 300, [&](hipStream_t s) { launch_skinny_gemm(a, s); }, (double)N * K + (double)M * K * 4 + (double)M * N * 4 * splits, 2.0 * M * N * K);
 }
 
+// int8 product on activations quantised by their producer; cq: the result leaves quantised too (the FFN-1 form)
+static void bench_skinny_q8p(const char* name, int M, int N, int K, int splits, bool cq) {
+    auto w = rnd((size_t)N * K);
+    std::vector<float> sc;
+    auto bytes = pack_q8_weight(w.data(), N, K, sc);
+    void* wp = nullptr;
+    CK(hipMalloc(&wp, bytes.size()));
+    CK(hipMemcpy(wp, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    float* sp = (float*)dalloc(sc.size() * 4);
+    const int Mq = (M + 15) & ~15;
+    SkinnyArgs a;
+    a.Aq = (const signed char*)dalloc((size_t)M * K); a.ldaq = K; a.Ad = (const float*)dalloc((size_t)(K / 64) * Mq * 4); a.Mq = Mq;
+    a.Wp = wp; a.wtype = W_I8; a.wscale = sp;
+    a.M = M; a.N = N; a.K = K; a.splits = splits;
+    if (cq) { a.Cq = (signed char*)dalloc((size_t)M * N, 0); a.Cd = (float*)dalloc((size_t)(N / 64) * Mq * 4, 0); a.act = ACT_GELU; }
+    else if (splits > 1) a.P = (float*)dalloc((size_t)splits * M * N * 4, 0);
+    else { a.C = (float*)dalloc((size_t)M * N * 4, 0); a.ldc = N; }
+    time_it(name, 300, [&](hipStream_t s) { launch_skinny_gemm(a, s); }, (double)N * K + (double)M * K + (double)M * N * 4 * splits, 2.0 * M * N * K);
+}
+
 static void bench_gemm(const char* name, int M, int N, int K, int split_a, int lda = 0) {
     GemmArgs g;
     if (!lda) lda = K;
@@ -208,6 +228,18 @@ int main(int argc, char** argv) {
             std::snprintf(nm, sizeof nm, "q8 out mt%d sp4", mt); bench_skinny_q8(nm, 64, 1024, 1024, 4, mt);
             std::snprintf(nm, sizeof nm, "q8 ff2 mt%d sp8", mt); bench_skinny_q8(nm, 64, 1024, 4096, 8, mt);
         }
+    }
+    if (want("skinny_q8p")) {
+        bench_skinny_q8p("q8p qkv sp4", 64, 3072, 1024, 4, false);
+        bench_skinny_q8p("q8p qkv sp2", 64, 3072, 1024, 2, false);
+        bench_skinny_q8p("q8p qkv sp1", 64, 3072, 1024, 1, false);
+        bench_skinny_q8p("q8p out sp4", 64, 1024, 1024, 4, false);
+        bench_skinny_q8p("q8p out sp2", 64, 1024, 1024, 2, false);
+        bench_skinny_q8p("q8p ff1 cq", 64, 4096, 1024, 1, true);
+        bench_skinny_q8p("q8p ff1 f32", 64, 4096, 1024, 1, false);
+        bench_skinny_q8p("q8p ff2 sp8", 64, 1024, 4096, 8, false);
+        bench_skinny_q8p("q8p ff2 sp4", 64, 1024, 4096, 4, false);
+        bench_skinny_q8p("q8p ff2 sp16", 64, 1024, 4096, 16, false);
     }
     if (want("skinny_ada")) {
         for (int mt : {4, 2, 1})

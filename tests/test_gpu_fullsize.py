@@ -169,6 +169,38 @@ def test_full_int8_graphs_and_offline_parity(full):
     eng.close()
 
 
+def test_int8_prequantised_step_matches_staged(full):
+    """The int8 decode step with activations quantised by their producers (add & norm, attention, FFN-1 epilogue)
+    against the same step with the products quantising while they stage f32 rows (POCKET_TTS_Q8_STAGED=1): the
+    scheme and the order of the float operations are the same, so the conditioning and EOS outputs agree to the last
+    bits, on 64 rows with ragged contexts over three steps."""
+    spec = full["spec"]
+    rng = np.random.default_rng(31)
+    embs = [(rng.standard_normal((5 + (11 * i) % 40, spec.d_model)) * 0.5).astype(np.float32) for i in range(64)]
+    seqs = [np.full((64, spec.latent_dim), np.nan, np.float32)] + [(rng.standard_normal((64, spec.latent_dim)) * 0.7).astype(np.float32) for _ in range(2)]
+    outs = []
+    for staged in (False, True):
+        if staged:
+            os.environ["POCKET_TTS_Q8_STAGED"] = "1"
+        try:
+            eng = full["lib"].Engine(full["path"], precision="int8", temperature=0.0, lsd_steps=10, max_frames=8)
+            st = eng.state(64)
+            for slot in range(64):
+                eng.lm_prefill(st, slot, embs[slot])
+            got = [eng.lm_step(st, sq) for sq in seqs]
+            outs.append(got)
+            st.close(); eng.close()
+        finally:
+            os.environ.pop("POCKET_TTS_Q8_STAGED", None)
+    worst, differing = 0.0, []
+    for (c0, e0), (c1, e1) in zip(*outs):
+        worst = max(worst, float(np.abs(c0 - c1).max()), float(np.abs(e0 - e1).max()))
+        differing.append(float((np.abs(c0 - c1) > 1e-6).mean()))
+    _note(f"int8 full size: decode step with producer-side quantisation vs staged quantisation, max-abs {worst:.3e}, "
+          f"share of conditioning elements that differ per step {differing}")
+    assert worst <= 1e-5, worst
+
+
 def test_int8_product_is_exact(full):
     """The int8 kernel against a numpy restatement of the scheme on identical inputs: every rounding decision is
     then the same, the block sums are integers, and only the float32 scaling differs in its last bits."""
