@@ -9,6 +9,13 @@
 
 namespace ptts {
 
+// A kernel launch reports a bad configuration (grid, LDS size, missing code object) only through the thread's last
+// error; the passes below ask for it once at their end so that such a launch cannot go by unnoticed.
+void check_launches(const char* where) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw std::runtime_error(std::string("kernel launch failed in ") + where + ": " + hipGetErrorString(e));
+}
+
 // ------------------------------------------------------------------------------------------ Model
 
 namespace {
@@ -701,6 +708,7 @@ void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc,
         else { f2.C = X; f2.ldc = d; }
         launch_gemm(f2, st);
     }
+    check_launches("the transformer pass");
 }
 
 // K-slices for a split-K product: about 256 deep each, at most 8, dividing K into k-step multiples.
@@ -791,6 +799,7 @@ void Engine::lm_rows_skinny(Batch& b, int slot0, int nb, int rpb, float* X) {
         else { a2.g = nullptr; a2.b = nullptr; a2.H = nullptr; }
         launch_add_norm(a2, st);
     }
+    check_launches("the short prefill pass");
 }
 
 // sequence[B][latent] (NaN = BOS) -> conditioning[B][d_model], eos[B]   (src/pocket_tts.cpp:323-411, decode shape)
@@ -881,6 +890,7 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         }
         launch_add_norm(a2, b.st);
     }
+    check_launches("the LM frame step");
 }
 
 // Host mirror of the positions one decode step consumes; call once per step actually run.
@@ -930,6 +940,7 @@ void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long
         fa.latents = b.latents.f(); fa.max_frames = opt_.max_frames;
     }
     launch_flow_head(fa, b.st);
+    check_launches("the flow phase");
 }
 
 // latent rows (batched mapping: utterance b at lat_dev + b*lat_bs, n rows of `latent` floats)
@@ -1034,6 +1045,7 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
     launch_advance_pos(b.dec_pos.as<int>(), B, T0, st);
     b.dec_pos_host += T0;
     phase_end(2, st);
+    check_launches("the decoder chunk");
 }
 
 }  // namespace ptts

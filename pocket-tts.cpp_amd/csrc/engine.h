@@ -22,6 +22,10 @@
 
 namespace ptts {
 
+// Throws if a kernel launch since the last call left an error behind (bad grid or LDS size, missing code object).
+void check_launches(const char* where);
+
+
 // float32 -> nearest-even bfloat16 bits
 inline uint16_t f32_to_bf16(float f) {
     uint32_t u;

@@ -591,6 +591,7 @@ std::vector<float> Engine::encode_voice(const float* audio, int S) {
     GemmArgs sp;
     sp.A = d2; sp.lda = M; sp.W = hd_.enc_spk.p; sp.wtype = hd_.enc_spk.wtype; sp.M = Nv; sp.N = D; sp.K = M; sp.C = o; sp.ldc = D;
     launch_gemm(sp, stream_);
+    check_launches("the voice encoder");
     std::vector<float> out(static_cast<size_t>(Nv) * D);
     PTTS_HIP(hipMemcpyAsync(out.data(), o, out.size() * 4, hipMemcpyDeviceToHost, stream_));
     PTTS_HIP(hipStreamSynchronize(stream_));
