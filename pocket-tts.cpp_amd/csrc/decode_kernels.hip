@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     const int r = lane & 15, g = lane >> 4;
     // the epilogue's bias is requested with the first operands, not after the last product
     const float bias_col = (a.bias && !a.P && tile_live) ? a.bias[nt * 16 + r] : 0.f;
+    const float cs_col = (a.colscale && !a.P && tile_live) ? a.colscale[nt * 16 + r] : 1.f;
 
     load_chunk(0);
     for (int c = 0; c < nchunks; ++c) {
@@ -160,7 +161,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
             if (a.P) {
                 a.P[((long long)blockIdx.y * a.M + row) * a.N + col] = v;
             } else {
-                a.C[(long long)row * a.ldc + col] = act_dev(v + bias_col, a.act);
+                v = act_dev(v + bias_col, a.act);
+                if (a.colscale) v *= cs_col;
+                if (a.R) v += a.R[(long long)row * a.ldr + col];
+                a.C[(long long)row * a.ldc + col] = v;
             }
         }
     }
@@ -433,6 +437,7 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
         return;
     }
     if (a.Cq) throw std::runtime_error("skinny gemm: a quantised result is produced from quantised activations only");
+    if ((a.colscale || a.R) && (a.P || a.wtype == W_I8)) throw std::runtime_error("skinny gemm: column scale and residual belong to the f32 / bf16 C form");
     grid.z = (a.M + 16 * mt - 1) / (16 * mt);
     if (a.wtype == W_I8) {
         if (mt == 1) hipLaunchKernelGGL(skinny_q8_kernel<1>, grid, block, 0, s, a);

@@ -193,6 +193,22 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
             ada_packed = extra_.back().p;
         }
     }
+    // decoder matrices whose products are short and deep when one utterance streams (5 frames = 80 rows): the Mimi
+    // transformer's and the first convolution's; fragment-major copies let those go to the skinny kernels
+    {
+        std::vector<std::string> small = {"dec.conv0.w"};
+        for (int i = 0; i < s.mimi_layers; ++i)
+            for (const char* t : {"qkv.w", "out.w", "ff1.w", "ff2.w"}) small.push_back("dec.t" + std::to_string(i) + "." + t);
+        for (auto& n : small) {
+            const HostTensor& t = pack.get(n);
+            const int wt = entries_[n].has_lp ? W_BF16 : W_F32;
+            if (t.shape.size() != 2 || t.shape[0] % 16 || t.shape[1] % (wt == W_BF16 ? 32 : 16)) continue;
+            auto bytes = pack_flow_weight(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), wt);
+            extra_.emplace_back(bytes.size());
+            PTTS_HIP(hipMemcpy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+            frag_[n] = extra_.back().p;
+        }
+    }
     {   // the voice encoder always runs on f32 weights
         const HostTensor& t = pack.get("enc.down.w");
         if (t.shape.size() == 2 && t.shape[0] % 16 == 0 && t.shape[1] % 16 == 0) {
@@ -249,6 +265,8 @@ DevWeight Model::w(const std::string& name) const {
         d.p = static_cast<const unsigned char*>(blob_f32_.p) + e.off_f32;
         d.wtype = W_F32;
     }
+    auto fr = frag_.find(name);
+    if (fr != frag_.end()) d.frag = fr->second;
     return d;
 }
 
@@ -669,6 +687,17 @@ void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc,
                          int window, const float* cos_tab, const float* sin_tab, int tab_len, const TfScratch& b, float* last_out,
                          long long last_bs, int last_ld, hipStream_t st, bool split_a) {
     const int M = nb * rpb;
+    // One utterance's short pass (a streaming chunk of the decoder): the tiled GEMM would run 16 to 64 workgroups
+    // through K loops of up to 2048; the skinny kernels cut the same products into 16-row x 64-column workgroups.
+    bool thin = nb == 1 && M <= 256 && !std::getenv("POCKET_TTS_NO_THIN_PASS");
+    for (auto& w : layers) thin = thin && w.qkv.frag && w.out.frag && w.ff1.frag && w.ff2.frag;
+    auto thin_linear = [&](const DevWeight& w, const float* A, int lda, float* C, int ldc, int N, int K, int act, const float* colscale,
+                           const float* R, int ldr) {
+        SkinnyArgs k;
+        k.A = A; k.lda = lda; k.Wp = w.frag; k.wtype = w.wtype; k.M = M; k.N = N; k.K = K; k.act = act;
+        k.C = C; k.ldc = ldc; k.colscale = colscale; k.R = R; k.ldr = ldr;
+        launch_skinny_gemm(k, st);
+    };
     for (size_t l = 0; l < layers.size(); ++l) {
         const TfLayer& w = layers[l];
         LayerNormArgs ln;
@@ -677,7 +706,8 @@ void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc,
         GemmArgs g;
         g.A = b.h; g.lda = d; g.W = w.qkv.p; g.wtype = w.qkv.wtype; g.C = b.qkv; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d;
         g.split_a = split_a;
-        launch_gemm(g, st);
+        if (thin) thin_linear(w.qkv, b.h, d, b.qkv, 3 * d, 3 * d, d, ACT_NONE, nullptr, nullptr, 0);
+        else launch_gemm(g, st);
         RopeAppendArgs r;
         const long long kv_off = static_cast<long long>(l) * layer_stride * (kv16 ? 2 : 4);
         r.qkv = b.qkv; r.q_out = b.q; r.kcache = static_cast<char*>(kc) + kv_off; r.vcache = static_cast<char*>(vc) + kv_off; r.kv16 = kv16;
@@ -691,13 +721,15 @@ void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc,
         GemmArgs o;
         o.A = b.att; o.lda = d; o.W = w.out.p; o.wtype = w.out.wtype; o.C = X; o.ldc = d; o.R = X; o.ldr = d; o.colscale = w.ls1;
         o.M = M; o.N = d; o.K = d; o.split_a = split_a;
-        launch_gemm(o, st);
+        if (thin) thin_linear(w.out, b.att, d, X, d, d, d, ACT_NONE, w.ls1, X, d);
+        else launch_gemm(o, st);
         ln.g = w.ln2g; ln.b = w.ln2b;
         launch_layernorm(ln, st);
         GemmArgs f1;
         f1.A = b.h; f1.lda = d; f1.W = w.ff1.p; f1.wtype = w.ff1.wtype; f1.C = b.ff; f1.ldc = ffn; f1.act_pre = ACT_GELU;
         f1.M = M; f1.N = ffn; f1.K = d; f1.split_a = split_a;
-        launch_gemm(f1, st);
+        if (thin) thin_linear(w.ff1, b.h, d, b.ff, ffn, ffn, d, ACT_GELU, nullptr, nullptr, 0);
+        else launch_gemm(f1, st);
         GemmArgs f2;
         f2.A = b.ff; f2.lda = ffn; f2.W = w.ff2.p; f2.wtype = w.ff2.wtype; f2.R = X; f2.ldr = d; f2.colscale = w.ls2;
         f2.M = M; f2.N = d; f2.K = ffn; f2.split_a = split_a;
@@ -706,7 +738,8 @@ void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc,
             f2.r_bs = (long long)rpb * d; f2.a_bs = (long long)rpb * ffn;
         }
         else { f2.C = X; f2.ldc = d; }
-        launch_gemm(f2, st);
+        if (thin) thin_linear(w.ff2, b.ff, ffn, f2.C, f2.ldc, d, ffn, ACT_NONE, w.ls2, X, d);   // one utterance: no row remapping
+        else launch_gemm(f2, st);
     }
     check_launches("the transformer pass");
 }
@@ -977,7 +1010,14 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
         a.A = b.ybuf.f(); a.a_bs = ybs; a.lda = M; a.rpb = T0; a.W = w.p; a.wtype = w.wtype; a.bias = hd_.dec_conv0_b;
         a.M = B * T0; a.N = c; a.K = s.kernel * M;
         a.C = b.e0buf.f() + c; a.c_bs = static_cast<long long>(1 + T0max) * c; a.ldc = c; a.c_act = ACT_ELU;
-        launch_gemm(a, st);
+        if (B == 1 && T0 <= 256 && w.frag && !std::getenv("POCKET_TTS_NO_THIN_PASS")) {
+            SkinnyArgs k;   // 80 rows against K = 7 * 512: 16 workgroups as a tiled GEMM
+            k.A = a.A; k.lda = a.lda; k.Wp = w.frag; k.wtype = w.wtype; k.M = T0; k.N = c; k.K = a.K; k.bias = a.bias; k.act = ACT_ELU;
+            k.C = a.C; k.ldc = c;
+            launch_skinny_gemm(k, st);
+        } else {
+            launch_gemm(a, st);
+        }
     }
     const float* prev = b.e0buf.f();
     long long prev_bs = static_cast<long long>(1 + T0max) * c;

@@ -12,6 +12,7 @@
 #include <deque>
 #include <exception>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <random>
 #include <string>
@@ -42,6 +43,7 @@ struct DevWeight {
     const void* p = nullptr;
     int wtype = W_F32;
     int N = 0, K = 0;
+    const void* frag = nullptr;   // fragment-major copy for the skinny kernels (same type), where the model keeps one
 };
 
 struct TfLayer {
@@ -88,6 +90,7 @@ private:
     std::map<std::string, Entry> entries_;
     DevBuf blob_f32_, blob_lp_, rope_;
     std::vector<DevBuf> extra_;
+    std::map<std::string, const void*> frag_;   // fragment-major copies by tensor name
 };
 
 struct EngineOptions {

@@ -168,6 +168,8 @@ struct SkinnyArgs {
     const float* bias = nullptr; int act = ACT_NONE;
     float* C = nullptr; int ldc = 0;
     float* P = nullptr;
+    // C form only (f32 / bf16 weights): C = act(acc + bias) * colscale + R
+    const float* colscale = nullptr; const float* R = nullptr; int ldr = 0;
     const float* wscale = nullptr;   // W_I8: per-output-column weight scale
     int mtiles = 0;                  // 16-row tiles per workgroup: 1, 2 or 4 (0 = 4)
     int kchunk = 0;                  // K elements staged per step: 128, 256 or 512 (bf16, mtiles <= 2); 0 = 128
