@@ -32,6 +32,17 @@ void Engine::prefill_utterance(Batch& b, int slot, const Utterance& u) {
     if (u.token_ids.empty()) throw std::runtime_error("Text cannot be empty");
     if (static_cast<int>(u.token_ids.size()) > opt_.max_text_tokens) throw std::runtime_error("text has more tokens than the engine was sized for");
     const int chunk = 256;
+    const int T_all = static_cast<int>(u.token_ids.size());
+    if (u.voice_frames + T_all <= chunk && !std::getenv("POCKET_TTS_TWO_PASS_PREFILL")) {
+        // One causal pass over [voice; text] writes the same KV cache as the two passes (the batched loop does the
+        // same) and halves the number of launches before the first frame.
+        if (u.voice_frames)
+            PTTS_HIP(hipMemcpyAsync(b.x.p, u.voice, static_cast<size_t>(u.voice_frames) * D * 4, hipMemcpyHostToDevice, stream_));
+        PTTS_HIP(hipMemcpyAsync(b.ids.p, u.token_ids.data(), static_cast<size_t>(T_all) * 8, hipMemcpyHostToDevice, stream_));
+        launch_embed_rows(b.ids.as<long long>(), T_all, hd_.text_embed, s.vocab + 1, D, b.x.f() + static_cast<size_t>(u.voice_frames) * D, stream_);
+        lm_rows(b, slot, 1, u.voice_frames + T_all, b.x.f());
+        return;
+    }
     for (int r0 = 0; r0 < u.voice_frames; r0 += chunk) {
         int n = std::min(chunk, u.voice_frames - r0);
         PTTS_HIP(hipMemcpyAsync(b.x.p, u.voice + static_cast<size_t>(r0) * D, static_cast<size_t>(n) * D * 4, hipMemcpyHostToDevice, stream_));
@@ -408,7 +419,7 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
         ensure_frame_graph(b);
         b.lm_pos_host = keep;
     }
-    PTTS_HIP(hipStreamSynchronize(st));
+    if (any_noise) PTTS_HIP(hipStreamSynchronize(st));   // h_x0 (the BOS upload's source) is refilled with the first start point
 
     std::vector<float> chunk_audio;
     auto flush = [&](int first, int count, bool is_final) {
