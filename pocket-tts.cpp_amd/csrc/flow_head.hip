@@ -310,7 +310,6 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
     static_assert(NT % G == 0 && KS % G == 0 && L % KSTEP == 0, "flow head: split does not tile");
     static_assert(kFlowWaves % KP1 == 0 && KS % KP1 == 0 && (size_t)kFlowWaves * T1 * 256 <= (size_t)16 * C, "flow head: fc1 K split over waves does not tile");
     static_assert(RPW * kFlowWaves >= 16 || RPW == 1, "flow head: rows per wave");
-    static_assert(!(FIN && ONE), "flow head: the one-row form has no fused tail");
     float* hbuf = (float*)smem_raw;                         // [16][C]   (first block only)
     WT* A0 = (WT*)(hbuf + 16 * C);                          // [PL][16][lda]
     WT* A1 = A0 + (PL - 1) * 16 * lda;
@@ -393,7 +392,8 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
                 __syncthreads();
                 f32x4 acco = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < KSP; ++ks) mma_frag<WT>(A0, A1, lda, (kpo * KSP + ks) * KSTEP, wo[ks], acco, lane);
+                for (int ks = 0; ks < KSP; ++ks) mma_frag<WT, ONE>(A0, A1, lda, (kpo * KSP + ks) * KSTEP, wo[ks], acco, lane);
+                one_row_finish<ONE>(acco);
                 float* redo = hbuf;                            // [waves][256]; hbuf is not in use yet
                 *(f32x4*)(redo + wave * 256 + lane * 4) = acco;
                 __syncthreads();
@@ -995,6 +995,7 @@ void flow_head_prepare(int C, int wtype) {
             else {
                 prepare_chain<float, 512, false>(); prepare_chain<float, 512, false, 8, 1>();
                 set_lds_limit((const void*)flow_block_kernel<float, 512, 8, 32, false, 1, false, true>, 128 * 1024);
+                set_lds_limit((const void*)flow_block_kernel<float, 512, 8, 32, false, 1, true, true>, 128 * 1024);
                 set_lds_limit((const void*)flow_final_kernel<float, 512, 8, 32, 1, true>, 128 * 1024);
             }
             break;
@@ -1009,7 +1010,8 @@ int flow_head_launch_count(const FlowHeadArgs& a) {
     const bool bf = a.wtype == W_BF16, q8 = a.block_wtype == W_I8;
     int G = 4, rpg = 16;
     flow_head_shape(a.C, a.B, bf, G, rpg);
-    const bool fused = a.C == 512 && bf && !q8 && G != 8 && rpg <= 8 && !std::getenv("FLOW_HEAD_NO_FUSE");
+    const bool fused = a.C == 512 && !std::getenv("FLOW_HEAD_NO_FUSE") &&
+                       (bf ? (!q8 && G != 8 && rpg <= 8) : (G == 8 && a.B == 1 && !std::getenv("FLOW_HEAD_NO_ONE_ROW")));
     return a.steps * a.blocks + (fused ? 1 : a.steps);
 }
 
@@ -1030,6 +1032,8 @@ void launch_flow_head(const FlowHeadArgs& a, hipStream_t s) {
             else if (bf && rpg <= 8 && !std::getenv("FLOW_HEAD_NO_FUSE")) run_chain<__bf16, 512, true, 4, 1, true>(a, s, rpg);
             else if (bf && rpg <= 8) run_chain<__bf16, 512, true, 4, 1>(a, s, rpg);
             else if (bf) run_chain<__bf16, 512, true>(a, s, rpg);
+            else if (!bf && G == 8 && a.B == 1 && !std::getenv("FLOW_HEAD_NO_ONE_ROW") && !std::getenv("FLOW_HEAD_NO_FUSE"))
+                run_chain<float, 512, false, 8, 1, true, true>(a, s, 4);
             else if (!bf && G == 8 && a.B == 1 && !std::getenv("FLOW_HEAD_NO_ONE_ROW")) run_chain<float, 512, false, 8, 1, false, true>(a, s, 4);
             else if (!bf && G == 8) run_chain<float, 512, false, 8, 1>(a, s, 8);   // one row per wave: two would spill (8 partials per row)
             else run_chain<float, 512, false>(a, s, rpg);
