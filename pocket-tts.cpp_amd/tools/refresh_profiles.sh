@@ -26,6 +26,7 @@ timeout -k 10 600 python3 bench.py > "$OUT/r01_bench.json"
 timeout -k 10 600 python3 bench.py --precision int8 --no-cpu-baseline > "$OUT/r01_bench_int8.json"
 timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/latency_probe.py --runs 20 > "$OUT/r01_latency_fp32.json"
 timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/latency_probe.py --runs 20 --precision bf16 > "$OUT/r01_latency_bf16.json"
+timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/latency_probe.py --runs 20 --precision int8 > "$OUT/r01_latency_int8.json"
 timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/encode_bench.py > "$OUT/r01_encode.json"
 rm -f gpurun_out/fullsize_parity.txt
 timeout -k 10 600 python3 -u -m pytest tests/test_gpu_fullsize.py -x -q --timeout 200 --timeout-method thread > "$OUT/fullsize_run.log" 2>&1
