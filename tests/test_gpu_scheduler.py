@@ -88,8 +88,56 @@ def test_drop_in_c_api_end_to_end(packs, tmp_path):
     total = L.pocket_tts_generate_streaming(h, b"hello from the test", v, cb, C.byref(sc))
     assert total == 7 * spec.frame_size
     assert got == [(3 * spec.frame_size, 0), (3 * spec.frame_size, 0), (spec.frame_size, 1)]
+    # cancellation from inside the callback (the reference polls the flag before every frame, src/pocket_tts.cpp:745-750,
+    # and skips the tail flush, :897): the chunk in hand is the last one, nothing is marked final
+    got2 = []
+
+    def on_chunk(p, n, fin, u):
+        got2.append((n, fin))
+        L.pocket_tts_cancel_streaming(h)
+
+    cb2 = ptts_lib.CHUNK_CB(on_chunk)
+    total2 = L.pocket_tts_generate_streaming(h, b"hello from the test", v, cb2, C.byref(sc))
+    assert got2 == [(3 * spec.frame_size, 0)] and total2 == 3 * spec.frame_size
+    # the flag is cleared at the start of the next call (:698)
+    got.clear()
+    assert L.pocket_tts_generate_streaming(h, b"hello from the test", v, cb, C.byref(sc)) == 7 * spec.frame_size
+    assert [f for _, f in got] == [0, 0, 1]
+    # a chunk size beyond the utterance: one final chunk
+    got.clear()
+    sc_big = ptts_lib.StreamingConfig(chunk_size_frames=50, user_data=None)
+    assert L.pocket_tts_generate_streaming(h, b"hello from the test", v, cb, C.byref(sc_big)) == 7 * spec.frame_size
+    assert got == [(7 * spec.frame_size, 1)]
     # empty text is an error reported through get_last_error, not a crash
     assert L.pocket_tts_generate(h, b"   ", v, C.byref(res)) == -1
     assert b"Text cannot be empty" in L.pocket_tts_get_last_error()
     L.pocket_tts_free_voice(v)
     L.pocket_tts_destroy(h)
+
+
+def test_size_limits_and_recovery(packs, oracle_mod):
+    """Inputs at and beyond the sizes an engine was created for: too many tokens and a context longer than the KV cache are
+    errors that leave the engine usable; no voice rows and a one-token text are valid inputs and match the oracle."""
+    import ptts_lib
+    from conftest import oracle_replay
+    path, spec, _ = packs["small"]
+    eng = ptts_lib.Engine(path, precision="fp32", temperature=0.0, lsd_steps=4, max_frames=4, max_text_tokens=8)
+    rng = np.random.default_rng(3)
+    voice = (rng.standard_normal((6, spec.d_model)) * 0.5).astype(np.float32)
+    with pytest.raises(ptts_lib.PttsError, match="more tokens"):
+        eng.generate_ids([rng.integers(0, spec.vocab, 9).astype(np.int64)], [voice])
+    long_voice = (rng.standard_normal((400, spec.d_model)) * 0.5).astype(np.float32)     # cache holds 64 + 8 + 4 + 8 -> 128 rows
+    with pytest.raises(ptts_lib.PttsError, match="KV-cache capacity"):
+        eng.generate_ids([rng.integers(0, spec.vocab, 5).astype(np.int64)], [long_voice])
+    with pytest.raises(ptts_lib.PttsError, match="KV-cache capacity"):
+        eng.streaming_ids(rng.integers(0, spec.vocab, 5).astype(np.int64), long_voice, chunk_frames=2)
+    o = oracle_mod.Oracle(path)
+    cases = [(rng.integers(0, spec.vocab, 8).astype(np.int64), voice),                                   # the token limit itself
+             (rng.integers(0, spec.vocab, 1).astype(np.int64), voice),                                   # one token
+             (rng.integers(0, spec.vocab, 4).astype(np.int64), np.zeros((0, spec.d_model), np.float32))]  # no voice rows
+    res = eng.generate_ids([c[0] for c in cases], [c[1] for c in cases])
+    for (ids, vo), r in zip(cases, res):
+        lat, eos, frames = oracle_replay(o, ids, vo, r["latents"], 4, 4)
+        assert r["frames"] == frames
+        assert np.abs(r["latents"] - lat).max() < 1e-3 and np.abs(r["eos"] - eos).max() < 1e-3
+    eng.close()
