@@ -60,22 +60,35 @@ __global__ __launch_bounds__(256) void resblock_kernel(ResblockArgs a) {
     const int li = lane & 15, g4 = lane >> 4;
     const int rw = w * 32;                            // this wave's first row inside the tile
     const int ntiles = (a.T + TM - 1) / TM;
+    // A tile's rows (t0 - 2 .. t0 + TM - 1 of the stream, 16 bytes per lane and piece) are requested one tile ahead, so
+    // that their way from HBM overlaps the previous tile's products and stores instead of heading a dependent chain.
+    constexpr int PPR = CO / 8, NPIECE = ((TM + HIST) * PPR + 255) / 256;
+    bf16x8 ynext[NPIECE];
+    auto request_tile = [&](int tile) {
+        const int t0n = tile * TM;
+#pragma unroll
+        for (int j = 0; j < NPIECE; ++j) {
+            const int i = tid + 256 * j, r = i / PPR, p = i % PPR;
+            bf16x8 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            if (i < (TM + HIST) * PPR && t0n + r < a.T + HIST) v = *(const bf16x8*)(Y + (long long)(t0n + r) * CO + 8 * p);
+            ynext[j] = v;
+        }
+    };
+    if ((int)blockIdx.x < ntiles) request_tile(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int t0 = tile * TM;
     __syncthreads();                                  // the previous tile's readers of As are done
-    // ---- stage the tile: rows t0 - 2 .. t0 + TM - 1 of the stream, 16 bytes per lane
-    {
-        constexpr int PPR = CO / 8;
-        for (int i = tid; i < (TM + HIST) * PPR; i += 256) {
-            const int r = i / PPR, p = i % PPR;
-            bf16x8 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-            if (t0 + r < a.T + HIST) v = *(const bf16x8*)(Y + (long long)(t0 + r) * CO + 8 * p);
-            bf16x8 e;
+    // ---- stage the tile: ELU, bf16
 #pragma unroll
-            for (int k = 0; k < 8; ++k) e[k] = (__bf16)elu_dev((float)v[k]);
-            *(bf16x8*)(As + r * LDA + 8 * p) = e;
-        }
+    for (int j = 0; j < NPIECE; ++j) {
+        const int i = tid + 256 * j, r = i / PPR, p = i % PPR;
+        if (i >= (TM + HIST) * PPR) continue;
+        bf16x8 e;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = (__bf16)elu_dev((float)ynext[j][k]);
+        *(bf16x8*)(As + r * LDA + 8 * p) = e;
     }
+    if (tile + (int)gridDim.x < ntiles) request_tile(tile + gridDim.x);
     __syncthreads();
     // ---- c1: H^T[CH][rows] = W1[CH][3 CO] . A^T
     f32x4 acc1[MT1][2];
