@@ -685,7 +685,7 @@ Batch* Engine::acquire_batch(int B, int lane) {
 void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc, int kv16, long long layer_stride, int cap,
                          const int* pos_dev, int slot0, int nb, int rpb, float* X, int d, int heads, int ffn, float eps,
                          int window, const float* cos_tab, const float* sin_tab, int tab_len, const TfScratch& b, float* last_out,
-                         long long last_bs, int last_ld, hipStream_t st, bool split_a) {
+                         long long last_bs, int last_ld, hipStream_t st, bool split_a, bool bf16_rows) {
     const int M = nb * rpb;
     // One utterance's short pass (a streaming chunk of the decoder): the tiled GEMM would run 16 to 64 workgroups
     // through K loops of up to 2048; the skinny kernels cut the same products into 16-row x 64-column workgroups.
@@ -698,14 +698,19 @@ void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc,
         k.C = C; k.ldc = ldc; k.colscale = colscale; k.R = R; k.ldr = ldr;
         launch_skinny_gemm(k, st);
     };
+    // bf16 rows between the kernels where the consumer rounds to bf16 once anyway (the normalised rows and the FFN's
+    // hidden rows): the same values, half the bytes
+    bool bfr = bf16_rows && !thin && !split_a && M >= 512 && (d & 7) == 0 && (ffn & 7) == 0;
+    for (auto& w : layers) bfr = bfr && w.qkv.wtype == W_BF16 && w.ff1.wtype == W_BF16 && w.ff2.wtype == W_BF16;
     for (size_t l = 0; l < layers.size(); ++l) {
         const TfLayer& w = layers[l];
         LayerNormArgs ln;
         ln.X = X; ln.ldx = d; ln.Y = b.h; ln.ldy = d; ln.M = M; ln.D = d; ln.g = w.ln1g; ln.b = w.ln1b; ln.eps = eps;
+        ln.y_bf16 = bfr;
         launch_layernorm(ln, st);
         GemmArgs g;
         g.A = b.h; g.lda = d; g.W = w.qkv.p; g.wtype = w.qkv.wtype; g.C = b.qkv; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d;
-        g.split_a = split_a;
+        g.split_a = split_a; g.a_bf16 = bfr;
         if (thin) thin_linear(w.qkv, b.h, d, b.qkv, 3 * d, 3 * d, d, ACT_NONE, nullptr, nullptr, 0);
         else launch_gemm(g, st);
         RopeAppendArgs r;
@@ -727,12 +732,12 @@ void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc,
         launch_layernorm(ln, st);
         GemmArgs f1;
         f1.A = b.h; f1.lda = d; f1.W = w.ff1.p; f1.wtype = w.ff1.wtype; f1.C = b.ff; f1.ldc = ffn; f1.act_pre = ACT_GELU;
-        f1.M = M; f1.N = ffn; f1.K = d; f1.split_a = split_a;
+        f1.M = M; f1.N = ffn; f1.K = d; f1.split_a = split_a; f1.a_bf16 = bfr; f1.c_bf16 = bfr;
         if (thin) thin_linear(w.ff1, b.h, d, b.ff, ffn, ffn, d, ACT_GELU, nullptr, nullptr, 0);
         else launch_gemm(f1, st);
         GemmArgs f2;
         f2.A = b.ff; f2.lda = ffn; f2.W = w.ff2.p; f2.wtype = w.ff2.wtype; f2.R = X; f2.ldr = d; f2.colscale = w.ls2;
-        f2.M = M; f2.N = d; f2.K = ffn; f2.split_a = split_a;
+        f2.M = M; f2.N = d; f2.K = ffn; f2.split_a = split_a; f2.a_bf16 = bfr;
         if (last_out && l + 1 == layers.size()) {
             f2.C = last_out; f2.c_bs = last_bs; f2.ldc = last_ld; f2.rpb = rpb;
             f2.r_bs = (long long)rpb * d; f2.a_bs = (long long)rpb * ffn;
@@ -1001,7 +1006,8 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
     const long long ybs = static_cast<long long>(H0 + T0max) * M;
     transformer(layers, b.dec_k.p, b.dec_v.p, b.kv16, static_cast<long long>(B) * b.dec_cap * M, b.dec_cap, b.dec_pos.as<int>(), 0, B, T0,
                 b.dx.f(), M, s.mimi_heads, s.mimi_ffn, s.mimi_eps, s.mimi_context, model_->mimi_cos, model_->mimi_sin,
-                model_->mimi_tab_len, b.dec_scratch(), b.ybuf.f() + static_cast<long long>(H0) * M, ybs, M, st);
+                model_->mimi_tab_len, b.dec_scratch(), b.ybuf.f() + static_cast<long long>(H0) * M, ybs, M, st, false,
+                std::getenv("POCKET_TTS_DECODER_F32_ROWS") == nullptr);
     // SEANet decoder
     int c = 8 * s.n_filters;
     {

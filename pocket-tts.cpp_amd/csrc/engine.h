@@ -200,7 +200,7 @@ private:
     void transformer(const std::vector<TfLayer>& layers, void* kc, void* vc, int kv16, long long layer_stride, int cap,
                      const int* pos_dev, int slot0, int nb, int rpb, float* X, int d, int heads, int ffn, float eps,
                      int window, const float* cos_tab, const float* sin_tab, int tab_len, const TfScratch& scratch,
-                     float* last_out, long long last_bs, int last_ld, hipStream_t st, bool split_a = false);
+                     float* last_out, long long last_bs, int last_ld, hipStream_t st, bool split_a = false, bool bf16_rows = false);
     void stage_part(Batch& b, const Utterance* utts, int n);
     // One frame of the autoregressive loop for a staged batch, free of host-side frame state (replayable as a graph):
     // LM step -> EOS logits to the host -> flow head from the start points of frame *step -> latent filed under *step.

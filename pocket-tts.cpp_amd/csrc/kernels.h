@@ -38,7 +38,8 @@ void launch_gemm(const GemmArgs& a, hipStream_t s);
 // Y[m][:] = (X[m][:] - mean) * rstd * g + b   (g, b may be null)
 struct LayerNormArgs {
     const float* X = nullptr; long long x_bs = 0; int ldx = 0;
-    float* Y = nullptr; long long y_bs = 0; int ldy = 0;
+    float* Y = nullptr; long long y_bs = 0; int ldy = 0;   // y_bf16: Y holds bf16 rows (strides in bf16 elements)
+    int y_bf16 = 0;
     int rpb = 1 << 30, M = 0, D = 0;
     const float* g = nullptr; const float* b = nullptr; float eps = 1e-5f;
 };

@@ -22,6 +22,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ------------------------------------------------------------------ LayerNorm: one wave per row
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_ln;
 __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
     const int b = m / a.rpb, t = m % a.rpb;
     const float* x = a.X + (long long)b * a.x_bs + (long long)t * a.ldx;
     float* y = a.Y + (long long)b * a.y_bs + (long long)t * a.ldy;
+    __bf16* y16 = (__bf16*)a.Y + (long long)b * a.y_bs + (long long)t * a.ldy;
     const int D = a.D;
     float s = 0.f;
     for (int i = lane * 4; i < D; i += 256) {
@@ -51,7 +53,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
             float4 g = *(const float4*)(a.g + i), bb = *(const float4*)(a.b + i);
             o.x = o.x * g.x + bb.x; o.y = o.y * g.y + bb.y; o.z = o.z * g.z + bb.z; o.w = o.w * g.w + bb.w;
         }
-        *(float4*)(y + i) = o;
+        if (a.y_bf16) {
+            bf16x4_ln o16;
+            o16[0] = (__bf16)o.x; o16[1] = (__bf16)o.y; o16[2] = (__bf16)o.z; o16[3] = (__bf16)o.w;
+            *(bf16x4_ln*)(y16 + i) = o16;
+        } else {
+            *(float4*)(y + i) = o;
+        }
     }
 }
 
