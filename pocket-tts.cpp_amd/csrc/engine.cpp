@@ -397,7 +397,7 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     }
     audio.alloc(static_cast<size_t>(B) * kDecChunk * s.frame_size() * 4);
     PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_eos), static_cast<size_t>(B) * 4));
-    PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_x0), static_cast<size_t>(B) * L * 4));
+    PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_x0), static_cast<size_t>(3) * B * L * 4));   // BOS rows + two sets of start points
     PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_eos_all), static_cast<size_t>(o.max_frames) * B * 4, hipHostMallocMapped));
     PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_flag), 64, hipHostMallocMapped));
     *h_flag = 0;

@@ -419,7 +419,6 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
         ensure_frame_graph(b);
         b.lm_pos_host = keep;
     }
-    if (any_noise) PTTS_HIP(hipStreamSynchronize(st));   // h_x0 (the BOS upload's source) is refilled with the first start point
 
     std::vector<float> chunk_audio;
     auto flush = [&](int first, int count, bool is_final) {
@@ -441,8 +440,10 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
         if (poll_cancel && cancel_flag && cancel_flag->load()) break;                      // :745-750
         lm_bookkeeping(b);
         if (any_noise) {
-            fill_noise(rngs, one, step, b.h_x0);
-            PTTS_HIP(hipMemcpyAsync(b.x0.p, b.h_x0, static_cast<size_t>(L) * 4, hipMemcpyHostToDevice, st));
+            // two pinned sets in turn, behind the BOS rows: the copy of frame k - 2 has run by now (its frame's EOS was seen)
+            float* hx = b.h_x0 + static_cast<size_t>(1 + (step & 1)) * L;
+            fill_noise(rngs, one, step, hx);
+            PTTS_HIP(hipMemcpyAsync(b.x0.p, hx, static_cast<size_t>(L) * 4, hipMemcpyHostToDevice, st));
         }
         if (graph) PTTS_HIP(hipGraphLaunch(b.frame_exec[step & 1], st));                     // :753, :777-784
         else frame_body(b, step & 1);
@@ -454,7 +455,6 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
         if (capture) capture->eos.push_back(e);
         if (e > kEosThreshold && eos_step < 0) eos_step = step;                            // :758
         if (eos_step >= 0 && step >= eos_step + opt_.frames_after_eos) break;              // :763 (this step's flow output is not used)
-        if (any_noise) PTTS_HIP(hipStreamSynchronize(st));                                 // h_x0 is rewritten next frame
         ++frames; ++pending;
         if (pending >= chunk_frames) {                                                     // :790 (the second clause cannot hold here)
             flush(frames - pending, pending, false);

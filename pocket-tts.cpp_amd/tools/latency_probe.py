@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--runs", type=int, default=10)
     ap.add_argument("--chunks", default="1,5,10")
+    ap.add_argument("--temperature", type=float, default=0.0)
     args = ap.parse_args()
     import ptts_pack as pp
     import ptts_lib
@@ -23,7 +24,7 @@ def main():
     voice = (np.random.default_rng(2).standard_normal((62, spec.d_model)) * 0.5).astype(np.float32)
     out = {}
     for c in [int(x) for x in args.chunks.split(",")]:
-        eng = ptts_lib.Engine(path, precision=args.precision, temperature=0.0, lsd_steps=10, max_frames=max(c, 10))
+        eng = ptts_lib.Engine(path, precision=args.precision, temperature=args.temperature, lsd_steps=10, max_frames=max(c, 10), seed=7)
         ts = []
         for i in range(args.runs + 2):
             _, _, t = eng.streaming_ids(ids, voice, chunk_frames=c)
