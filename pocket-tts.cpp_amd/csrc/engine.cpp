@@ -416,23 +416,32 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
 }
 
 // Grow the transformer scratch so that a pass over `rows` rows of width d (FFN width ffn) fits.
+// The captured frame graphs hold the addresses of x / h / qkv / att / ff (the decode step runs in them), so a
+// reallocation drops the graphs; the next run captures them again on the new buffers.
 void Batch::ensure_rows(size_t rows, int d, int ffn) {
     const size_t need_d = rows * d, need_f = rows * ffn;
     if (need_d > scratch_rows_d) {
         PTTS_HIP(hipDeviceSynchronize());
+        drop_graphs();
         x.alloc(need_d * 4); h.alloc(need_d * 4); q.alloc(need_d * 4); att.alloc(need_d * 4); qkv.alloc(need_d * 3 * 4);
         scratch_rows_d = need_d;
     }
     if (need_f > scratch_rows_f) {
         PTTS_HIP(hipDeviceSynchronize());
+        drop_graphs();
         ff.alloc(need_f * 4);
         scratch_rows_f = need_f;
     }
 }
 
-Batch::~Batch() {
+void Batch::drop_graphs() {
     for (auto& ex : frame_exec)
-        if (ex) (void)hipGraphExecDestroy(ex);
+        if (ex) { (void)hipGraphExecDestroy(ex); ex = nullptr; }
+    graph_x0 = nullptr; graph_x0_stride = -1;
+}
+
+Batch::~Batch() {
+    drop_graphs();
     for (auto& pair : tev)
         for (auto& ev : pair)
             if (ev) (void)hipEventDestroy(ev);
@@ -589,6 +598,7 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
         }
     }
     flow_head_prepare(s.flow_dim, model_->flow_wtype);
+    // STATIC_SCRATCH_HOOK
     flow_te_.alloc(te.size() * 4);
     PTTS_HIP(hipMemcpy(flow_te_.p, te.data(), te.size() * 4, hipMemcpyHostToDevice));
     PTTS_HIP(hipEventCreate(&ev_[0]));
@@ -942,6 +952,27 @@ void Engine::lm_bookkeeping(Batch& b) {
 // lsd_steps Euler iterations for B rows: 3 small launches for the adaLN vectors, then the head's per-block chain.
 void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B,
                       const int* x0_step, long long x0_step_stride, hipEvent_t probe_a, hipEvent_t probe_b, bool frame_mode) {
+    FlowScratch fs{b.cemb.f(), b.ymod.f(), b.mods.f(), b.flow_ws.f()};
+    flow_core(fs, b.st, cond_dev, x0_dev, x0_stride, x_out_dev, B, x0_step, x0_step_stride, probe_a, probe_b, frame_mode ? &b : nullptr);
+}
+
+// Bytes of the four scratch areas of a flow phase over `rows` rows, each rounded up to 256 bytes:
+// conditioning slabs, adaLN input rows, adaLN vectors, head workspace.
+void Engine::flow_scratch_layout(int rows, size_t off[5]) const {
+    const Spec& s = spec();
+    const int C = s.flow_dim, N = opt_.lsd_steps;
+    auto r256 = [](size_t n) { return (n + 255) & ~static_cast<size_t>(255); };
+    off[0] = 0;
+    off[1] = off[0] + r256(static_cast<size_t>(16) * rows * C * 4);
+    off[2] = off[1] + r256(static_cast<size_t>(N) * rows * C * 4);
+    off[3] = off[2] + r256(static_cast<size_t>(N) * rows * model_->mod_width * 4);
+    off[4] = off[3] + r256(flow_head_workspace_bytes(rows, C, model_->flow_wtype));
+}
+
+// frame (optional): the batch whose frame bookkeeping (EOS publication, frame counter, latent filing) rides in the launches
+void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_dev, const float* x0_dev, long long x0_stride,
+                       float* x_out_dev, int B, const int* x0_step, long long x0_step_stride, hipEvent_t probe_a, hipEvent_t probe_b,
+                       Batch* frame) {
     const Spec& s = spec();
     const int C = s.flow_dim, N = opt_.lsd_steps;
     // conditioning embedding as K-slice slabs (skinny product), summed inside the next kernel
@@ -949,35 +980,35 @@ void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long
     const int cs = pick_splits(s.d_model, wt == W_BF16 ? 32 : 16);
     SkinnyArgs g;
     g.A = cond_dev; g.lda = s.d_model; g.Wp = model_->flow_cond_packed; g.wtype = wt; g.M = B; g.N = C; g.K = s.d_model;
-    g.splits = cs; g.P = b.cemb.f();
-    launch_skinny_gemm(g, b.st);
+    g.splits = cs; g.P = fs.cemb;
+    launch_skinny_gemm(g, st);
     FramePublish pub;
-    if (frame_mode) { pub.eos = b.eos.f(); pub.step = b.step_dev.as<int>(); pub.h_eos_all = b.h_eos_all; pub.h_flag = b.h_flag; }
-    launch_flow_mod_input(flow_te_.f(), b.cemb.f(), cs, hd_.flow_cond_b, b.ymod.f(), N, B, C, b.st, frame_mode ? &pub : nullptr);
+    if (frame) { pub.eos = frame->eos.f(); pub.step = frame->step_dev.as<int>(); pub.h_eos_all = frame->h_eos_all; pub.h_flag = frame->h_flag; }
+    launch_flow_mod_input(flow_te_.f(), fs.cemb, cs, hd_.flow_cond_b, fs.ymod, N, B, C, st, frame ? &pub : nullptr);
     if (model_->ada_packed) {
         SkinnyArgs m;
-        m.A = b.ymod.f(); m.lda = C; m.Wp = model_->ada_packed; m.wtype = wt; m.M = N * B; m.N = model_->mod_width; m.K = C;
-        m.bias = model_->ada_all_b; m.C = b.mods.f(); m.ldc = model_->mod_width;
+        m.A = fs.ymod; m.lda = C; m.Wp = model_->ada_packed; m.wtype = wt; m.M = N * B; m.N = model_->mod_width; m.K = C;
+        m.bias = model_->ada_all_b; m.C = fs.mods; m.ldc = model_->mod_width;
         if (m.M > 128) { m.mtiles = 2; m.kchunk = 128; }   // measured at 640 x 10240 x 512: 32 us (64-row groups 39 us, tiled GEMM 66 us)
-        launch_skinny_gemm(m, b.st);
+        launch_skinny_gemm(m, st);
     } else {
         GemmArgs m;
-        m.A = b.ymod.f(); m.lda = C; m.W = model_->ada_all.p; m.wtype = model_->ada_all.wtype; m.C = b.mods.f(); m.ldc = model_->mod_width;
+        m.A = fs.ymod; m.lda = C; m.W = model_->ada_all.p; m.wtype = model_->ada_all.wtype; m.C = fs.mods; m.ldc = model_->mod_width;
         m.bias = model_->ada_all_b; m.M = N * B; m.N = model_->mod_width; m.K = C; m.split_a = 1;
-        launch_gemm(m, b.st);
+        launch_gemm(m, st);
     }
     FlowHeadArgs fa;
-    fa.x0 = x0_dev; fa.x0_stride = x0_stride; fa.x_out = x_out_dev; fa.mods = b.mods.f(); fa.B = B; fa.L = s.latent; fa.C = C; fa.blocks = s.flow_blocks;
+    fa.x0 = x0_dev; fa.x0_stride = x0_stride; fa.x_out = x_out_dev; fa.mods = fs.mods; fa.B = B; fa.L = s.latent; fa.C = C; fa.blocks = s.flow_blocks;
     fa.steps = N; fa.mod_width = model_->mod_width;
     fa.w_in = model_->flow_in_packed; fa.b_in = hd_.flow_in_b; fa.w_out = model_->flow_out_packed; fa.b_out = hd_.flow_out_b;
-    fa.host_tabs = &model_->flow_tabs; fa.workspace = b.flow_ws.f(); fa.wtype = model_->flow_wtype; fa.eps = s.flow_eps;
+    fa.host_tabs = &model_->flow_tabs; fa.workspace = fs.ws; fa.wtype = model_->flow_wtype; fa.eps = s.flow_eps;
     fa.block_wtype = model_->flow_block_wtype;
     fa.x0_step = x0_step; fa.x0_step_stride = x0_step_stride; fa.probe_a = probe_a; fa.probe_b = probe_b;
-    if (frame_mode) {   // the counter was advanced when the EOS logits were published: the frame index is *step - 1
-        fa.x0_step = b.step_dev.as<int>(); fa.x0_step_bias = -1;
-        fa.latents = b.latents.f(); fa.max_frames = opt_.max_frames;
+    if (frame) {   // the counter was advanced when the EOS logits were published: the frame index is *step - 1
+        fa.x0_step = frame->step_dev.as<int>(); fa.x0_step_bias = -1;
+        fa.latents = frame->latents.f(); fa.max_frames = opt_.max_frames;
     }
-    launch_flow_head(fa, b.st);
+    launch_flow_head(fa, st);
     check_launches("the flow phase");
 }
 

@@ -214,6 +214,10 @@ private:
     void flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B,
                   const int* x0_step = nullptr, long long x0_step_stride = 0, hipEvent_t probe_a = nullptr, hipEvent_t probe_b = nullptr,
                   bool frame_mode = false);   // frame_mode: EOS publication, frame counter and latent filing ride in the phase's launches
+    struct FlowScratch { float *cemb, *ymod, *mods, *ws; };
+    void flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev,
+                   int B, const int* x0_step, long long x0_step_stride, hipEvent_t probe_a, hipEvent_t probe_b, Batch* frame);
+    void flow_scratch_layout(int rows, size_t off[5]) const;
     void mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs, hipStream_t st);
     void prefill_utterance(Batch& b, int slot, const Utterance& u);
     void fill_noise(std::vector<std::mt19937>& rngs, const std::vector<Utterance>& utts, int step, float* host_x0);
@@ -293,6 +297,7 @@ public:
     DevBuf x, h, qkv, q, att, ff;
     size_t scratch_rows_d = 0, scratch_rows_f = 0;  // capacity in floats of x/h/q/att and of ff
     void ensure_rows(size_t rows, int d, int ffn);
+    void drop_graphs();   // destroys the captured frame graphs (they hold buffer addresses)
     DevBuf st_nv, st_nt, st_len;  // per-slot int arrays of the staged batch
     // LM I/O
     DevBuf seq_in, cond, eos, x0, xcur, latents, ids;

@@ -141,6 +141,31 @@ def test_bf16_latents_within_tolerance(ptts, packs, oracle_mod):
     eng.close()
 
 
+def test_frame_graph_survives_scratch_growth(ptts, packs, oracle_mod):
+    """A short call captures the frame graph of a 2-utterance batch; the next call on the same engine has a prefill
+    of 2 x 330 rows, which outgrows the transformer scratch the graph's decode step runs in.  The graph must be
+    captured again on the new buffers: the second call is checked against the oracle frame by frame, and a third,
+    short call against the first."""
+    path, spec, _ = packs["tiny"]
+    F = 5
+    eng = ptts.Engine(path, precision="fp32", temperature=0.0, lsd_steps=4, max_frames=F)
+    o = oracle_mod.Oracle(path)
+    rng = np.random.default_rng(71)
+    ids_s, voices_s = _inputs(spec, rng, 2, [6, 9], [4, 7])
+    ids_l, voices_l = _inputs(spec, rng, 2, [300, 250], [30, 12])
+    first = eng.generate_ids(ids_s, voices_s)
+    big = eng.generate_ids(ids_l, voices_l)
+    for i in range(2):
+        lat, eos, frames = oracle_replay(o, ids_l[i], voices_l[i], big[i]["latents"], 4, F)
+        assert big[i]["frames"] == frames == F
+        assert np.abs(big[i]["latents"] - lat).max() < 1e-3 and np.abs(big[i]["eos"] - eos).max() < 1e-3
+    again = eng.generate_ids(ids_s, voices_s)
+    for i in range(2):
+        np.testing.assert_array_equal(first[i]["latents"], again[i]["latents"])
+        np.testing.assert_array_equal(first[i]["audio"], again[i]["audio"])
+    eng.close()
+
+
 def test_error_conventions(ptts, packs):
     L = ptts.load()
     assert L.pocket_tts_version() == b"1.0.0"
