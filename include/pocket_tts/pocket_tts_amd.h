@@ -102,6 +102,17 @@ POCKET_TTS_API int ptts_lm_step(PocketTTSHandle handle, void* state, const float
  * cond[rows][d_model], x0[rows][latent_dim] -> x[rows][latent_dim]  (src/pocket_tts.cpp:414-451, 615-622). */
 POCKET_TTS_API int ptts_flow_euler(PocketTTSHandle handle, const float* cond, const float* x0, int rows, float* x);
 
+/* ptts_flow_euler for callers that cannot allocate device memory (code under HIP graph capture, serving loops and
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  cond, x0 and x are DEVICE pointers on the
+ * handle's GPU (x must not alias x0); the scratch the kernels need (adaLN vectors, partial-sum slabs) is a static
+ * device array of ptts_flow_euler_noalloc_capacity() bytes (32 MiB) that each GPU holds until the process ends.  The
+ * call allocates and frees nothing, returns when x is complete, and fails with a message that names the limit when
+ * `rows` needs more scratch than the array holds (full-size model at lsd_steps 10: 68 rows fit).  Calls on one GPU
+ * share that GPU's array: the library serialises its own calls per GPU; do not run two processes' worth of
+ * overlapping calls through other means. */
+POCKET_TTS_API int ptts_flow_euler_noalloc(PocketTTSHandle handle, const float* cond_dev, const float* x0_dev, int rows, float* x_dev);
+POCKET_TTS_API unsigned long long ptts_flow_euler_noalloc_capacity(void);
+
 /* mimi_decoder on one chunk: latents[batch][n][latent_dim], n <= 15 -> audio[batch][n*samples_per_frame]
  * with the state carried in `state`                                 (src/pocket_tts.cpp:463-543). */
 POCKET_TTS_API int ptts_mimi_decode(PocketTTSHandle handle, void* state, const float* latents, int n, float* audio);

@@ -400,6 +400,16 @@ POCKET_TTS_API int ptts_flow_euler(PocketTTSHandle handle, const float* cond, co
     });
 }
 
+POCKET_TTS_API int ptts_flow_euler_noalloc(PocketTTSHandle handle, const float* cond_dev, const float* x0_dev, int rows, float* x_dev) {
+    if (!handle || !cond_dev || !x0_dev || !x_dev || rows <= 0) { set_error("Invalid parameters"); return -1; }
+    return guarded("flow_euler_noalloc: ", [&] {
+        tts_of(handle)->engine().op_flow_euler_static(cond_dev, x0_dev, rows, x_dev);
+        return 0;
+    });
+}
+
+POCKET_TTS_API unsigned long long ptts_flow_euler_noalloc_capacity(void) { return ptts::Engine::static_scratch_capacity(); }
+
 POCKET_TTS_API int ptts_mimi_decode(PocketTTSHandle handle, void* state, const float* latents, int n, float* audio) {
     if (!handle || !state || !latents || !audio) { set_error("Invalid parameters"); return -1; }
     return guarded("mimi_decode: ", [&] {

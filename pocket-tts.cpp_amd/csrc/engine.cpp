@@ -598,7 +598,7 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
         }
     }
     flow_head_prepare(s.flow_dim, model_->flow_wtype);
-    // STATIC_SCRATCH_HOOK
+    init_static_scratch();
     flow_te_.alloc(te.size() * 4);
     PTTS_HIP(hipMemcpy(flow_te_.p, te.data(), te.size() * 4, hipMemcpyHostToDevice));
     PTTS_HIP(hipEventCreate(&ev_[0]));

@@ -183,6 +183,9 @@ public:
     void op_lm_prefill(Batch* b, int slot, const float* emb, int rows);
     void op_lm_step(Batch* b, const float* seq /*[B][latent]*/, float* cond /*[B][d_model]*/, float* eos /*[B]*/);
     void op_flow_euler(const float* cond, const float* x0, int B, float* x_out);
+    // The same on device buffers with the scratch in a static device array: no allocation of any kind (noalloc.cpp).
+    void op_flow_euler_static(const float* cond_dev, const float* x0_dev, int B, float* x_out_dev);
+    static size_t static_scratch_capacity();
     void op_mimi_decode(Batch* b, const float* latents /*[B][n][latent]*/, int n, float* audio /*[B][n*frame]*/);
     void q8_linear(const float* A, int M, int K, const float* W, int N, float* out);   // the int8 product kernel alone
     void bf16_linear(const float* A, int M, int K, const float* W, int N, const float* bias, const float* colscale, const float* R, int act,
@@ -243,6 +246,8 @@ private:
     std::mutex mu_;
     std::recursive_mutex call_mu_;
     std::mt19937 rng_;
+    unsigned char* static_scratch_ = nullptr;   // this device's copy of the static scratch array (noalloc.cpp)
+    void init_static_scratch();
     DevBuf flow_te_;  // [lsd_steps][C] averaged time embeddings of the fixed (s_j, t_j) grid
     DevBuf enc_arena_;   // every buffer of a voice-encoder pass, kept between calls
     std::map<std::pair<int, int>, std::unique_ptr<Batch>> batch_pool_;   // (rows, lane)

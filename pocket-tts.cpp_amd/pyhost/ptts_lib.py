@@ -50,7 +50,7 @@ EXT_SYMBOLS = [
     "pocket_tts_voice_data", "pocket_tts_generate_batch", "pocket_tts_generate_ids", "pocket_tts_streaming_ids",
     "pocket_tts_stage_ids", "pocket_tts_run_staged", "pocket_tts_fetch_staged",
     "pocket_tts_tokenize", "ptts_text_conditioner", "ptts_state_new", "ptts_state_free", "ptts_state_reset",
-    "ptts_lm_prefill", "ptts_lm_step", "ptts_flow_euler", "ptts_mimi_decode", "ptts_mimi_encode",
+    "ptts_lm_prefill", "ptts_lm_step", "ptts_flow_euler", "ptts_flow_euler_noalloc", "ptts_flow_euler_noalloc_capacity", "ptts_mimi_decode", "ptts_mimi_encode",
     "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_q8_linear", "ptts_bf16_linear",
     "ptts_tokenizer_new", "ptts_tokenizer_free", "ptts_tokenizer_vocab", "ptts_tokenizer_encode",
     "ptts_audio_load_wav", "ptts_audio_save_wav", "ptts_audio_resample", "ptts_audio_normalize",
@@ -108,6 +108,8 @@ def load() -> C.CDLL:
     L.ptts_lm_prefill.restype = ci; L.ptts_lm_prefill.argtypes = [vp, vp, ci, f32p, ci]
     L.ptts_lm_step.restype = ci; L.ptts_lm_step.argtypes = [vp, vp, f32p, f32p, f32p]
     L.ptts_flow_euler.restype = ci; L.ptts_flow_euler.argtypes = [vp, f32p, f32p, ci, f32p]
+    L.ptts_flow_euler_noalloc.restype = ci; L.ptts_flow_euler_noalloc.argtypes = [vp, vp, vp, ci, vp]
+    L.ptts_flow_euler_noalloc_capacity.restype = C.c_ulonglong; L.ptts_flow_euler_noalloc_capacity.argtypes = []
     L.ptts_mimi_decode.restype = ci; L.ptts_mimi_decode.argtypes = [vp, vp, f32p, ci, f32p]
     L.ptts_mimi_encode.restype = ci; L.ptts_mimi_encode.argtypes = [vp, f32p, ci, f32p, ci]
     L.ptts_phase_timing.restype = ci; L.ptts_phase_timing.argtypes = [vp, ci]
@@ -298,6 +300,10 @@ class Engine:
         out = np.empty((rows, self.latent), np.float32)
         _check(self.L.ptts_flow_euler(self.h, cond, x0, rows, out), "flow_euler")
         return out
+
+    def flow_euler_noalloc(self, cond_ptr: int, x0_ptr: int, rows: int, out_ptr: int) -> None:
+        """Device pointers in and out; the library allocates nothing (static scratch array)."""
+        _check(self.L.ptts_flow_euler_noalloc(self.h, cond_ptr, x0_ptr, rows, out_ptr), "flow_euler_noalloc")
 
     def mimi_decode(self, st: State, latents) -> np.ndarray:
         latents = np.ascontiguousarray(latents, np.float32)
