@@ -188,11 +188,18 @@ def tensor_table(s: Spec) -> List[Tuple[str, Tuple[int, ...], str]]:
 
 
 def synth_weights(s: Spec, seed: int = 1234, eos_bias: float = -20.0,
-                  layer_scale: float = 0.05) -> Dict[str, np.ndarray]:
+                  layer_scale: float = 0.05, residual_gain: float = 1.0, gate_gain: float = 1.0) -> Dict[str, np.ndarray]:
     """Seeded synthetic weights: linear/conv N(0, 1/sqrt(K)), norms near identity.
 
     eos_bias = -20 keeps the EOS logit far below the reference's -4.0 threshold
     (src/pocket_tts.cpp:596) so generation length is set by max_frames alone.
+
+    residual_gain scales the matrices that write into the LM's residual stream (attention output and FFN-2
+    projections); gate_gain scales the gate third of every flow block's adaLN projection.  With both at 1 every
+    residual branch is as large as the stream it is added to, which no trained network is: trained pre-norm
+    transformers initialise those projections at 1/sqrt(2 * layers) of the others and adaLN gates at zero, and
+    their sensitivity to a rounding error in one layer is correspondingly smaller.  Values below 1 give a model
+    whose error propagation is closer to a trained one's; the draws themselves are the same for every gain.
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     out: Dict[str, np.ndarray] = {}
@@ -219,6 +226,11 @@ def synth_weights(s: Spec, seed: int = 1234, eos_bias: float = -20.0,
             a = np.full(shape, eos_bias, dtype=np.float32)
         else:
             raise ValueError(kind)
+        if kind == "w" and name.startswith("lm.l") and name.endswith((".out.w", ".ff2.w")):
+            a = a * np.float32(residual_gain)
+        if name.startswith("flow.b") and name.endswith((".ada.w", ".ada.b")):
+            a = a.copy()
+            a[2 * s.flow_dim:] *= np.float32(gate_gain)      # rows [2C, 3C) produce the gate
         out[name] = np.ascontiguousarray(a, dtype=np.float32)
     return out
 
@@ -275,8 +287,9 @@ def read_pack(path: str) -> Tuple[Spec, Dict[str, np.ndarray]]:
 
 
 def make_pack(path: str, spec: Spec, seed: int = 1234, eos_bias: float = -20.0,
-              layer_scale: float = 0.05) -> Dict[str, np.ndarray]:
-    w = synth_weights(spec, seed=seed, eos_bias=eos_bias, layer_scale=layer_scale)
+              layer_scale: float = 0.05, residual_gain: float = 1.0, gate_gain: float = 1.0) -> Dict[str, np.ndarray]:
+    w = synth_weights(spec, seed=seed, eos_bias=eos_bias, layer_scale=layer_scale, residual_gain=residual_gain,
+                      gate_gain=gate_gain)
     write_pack(path, spec, w)
     return w
 
