@@ -57,10 +57,11 @@ def test_full_fp32_offline_parity(full):
 
 
 def test_full_bf16_offline_parity(full):
-    """Per-frame (same history on both sides) latent error of the bf16 engine.  The engine's model IS the
-    bf16-rounded weight set, so the 2e-2 bound is taken against the oracle evaluating that same model in
-    float32; the distance to the oracle on the unrounded weights (weight quantisation included) is recorded
-    and bounded at 5e-2."""
+    """Per-frame (same history on both sides) latent error of the bf16 engine's ARITHMETIC: against the oracle
+    evaluating the same bf16-rounded weights in float32, bound 2e-2.  The distance to the float32 model (weight
+    rounding included) is what the engine is specified to (2e-2); this random-weight model does not meet it
+    (4.2e-2 measured), which tests/test_gpu_configs.py reports as an expected failure with the bound unwidened.
+    The 5e-2 below is a regression guard at the measured level, not the specification."""
     eng = full["lib"].Engine(full["path"], precision="bf16", temperature=0.0, lsd_steps=10, max_frames=F)
     res = eng.generate_ids(full["ids"], full["voices"])
     worst_q = worst_f = 0.0
@@ -162,8 +163,10 @@ def test_full_int8_graphs_and_offline_parity(full):
     # Dynamic activation quantisation is discontinuous: the int8 ORACLE moves by ~4e-2 (LM conditioning, magnitude
     # ~3.5) and ~1e-2 (flow head) when its inputs are perturbed by 1e-6, because a handful of roundings flip.  Two
     # correct implementations therefore agree only to that noise floor; the kernel arithmetic itself is checked
-    # exactly in test_int8_product_is_exact.  Bounds: a few times the floor, and never further from the int8 oracle
-    # than int8 is from float.
+    # exactly in test_int8_product_is_exact.  The bounds below are regression guards at a few times that floor
+    # (and "never further from the int8 oracle than int8 is from float"), NOT the 2e-2 the int8 engine is specified
+    # to against the float32 model: that bound is kept, unwidened and as an expected failure (1.5e-1 measured here,
+    # 8.3e-2 on the residual-scaled pack), in tests/test_gpu_configs.py.
     assert e_flow <= 5e-2 and e_lm <= 1.5e-1
     assert worst <= 1.5 * worst_f and worst <= 3e-1
     eng.close()
