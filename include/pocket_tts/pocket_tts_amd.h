@@ -107,7 +107,7 @@ POCKET_TTS_API int ptts_flow_euler(PocketTTSHandle handle, const float* cond, co
  * handle's GPU (x must not alias x0); the scratch the kernels need (adaLN vectors, partial-sum slabs) is a static
  * device array of ptts_flow_euler_noalloc_capacity() bytes (32 MiB) that each GPU holds until the process ends.  The
  * call allocates and frees nothing, returns when x is complete, and fails with a message that names the limit when
- * `rows` needs more scratch than the array holds (full-size model at lsd_steps 10: 68 rows fit).  Calls on one GPU
+ * `rows` needs more scratch than the array holds (full-size model at lsd_steps 10: 59 rows fit).  Calls on one GPU
  * share that GPU's array: the library serialises its own calls per GPU; do not run two processes' worth of
  * overlapping calls through other means. */
 POCKET_TTS_API int ptts_flow_euler_noalloc(PocketTTSHandle handle, const float* cond_dev, const float* x0_dev, int rows, float* x_dev);

@@ -377,7 +377,9 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     cemb.alloc(static_cast<size_t>(16) * B * C * 4);   // up to 16 K-slice slabs
     ymod.alloc(static_cast<size_t>(o.lsd_steps) * B * C * 4);
     mods.alloc(static_cast<size_t>(o.lsd_steps) * B * e.model().mod_width * 4);
-    flow_ws.alloc(flow_head_workspace_bytes(B, C, e.model().flow_wtype));
+    flow_ws.alloc(flow_head_workspace_bytes(B, C, e.model().flow_wtype, s.flow_blocks));
+    flow_ctl.alloc(flow_ring_ctl_bytes(B, s.flow_blocks));
+    PTTS_HIP(hipMemset(flow_ctl.p, 0, flow_ctl.bytes));   // the error word is read after every run, whichever form of the head ran
     // decoder activations
     zbuf.alloc(static_cast<size_t>(B) * kDecChunk * L * 4);
     qbuf.alloc(static_cast<size_t>(B) * (1 + kDecChunk) * M * 4);
@@ -952,13 +954,13 @@ void Engine::lm_bookkeeping(Batch& b) {
 // lsd_steps Euler iterations for B rows: 3 small launches for the adaLN vectors, then the head's per-block chain.
 void Engine::flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B,
                       const int* x0_step, long long x0_step_stride, hipEvent_t probe_a, hipEvent_t probe_b, bool frame_mode) {
-    FlowScratch fs{b.cemb.f(), b.ymod.f(), b.mods.f(), b.flow_ws.f()};
+    FlowScratch fs{b.cemb.f(), b.ymod.f(), b.mods.f(), b.flow_ws.f(), b.flow_ctl.as<unsigned>()};
     flow_core(fs, b.st, cond_dev, x0_dev, x0_stride, x_out_dev, B, x0_step, x0_step_stride, probe_a, probe_b, frame_mode ? &b : nullptr);
 }
 
-// Bytes of the four scratch areas of a flow phase over `rows` rows, each rounded up to 256 bytes:
-// conditioning slabs, adaLN input rows, adaLN vectors, head workspace.
-void Engine::flow_scratch_layout(int rows, size_t off[5]) const {
+// Bytes of the five scratch areas of a flow phase over `rows` rows, each rounded up to 256 bytes:
+// conditioning slabs, adaLN input rows, adaLN vectors, head workspace, the persistent head's control words.
+void Engine::flow_scratch_layout(int rows, size_t off[6]) const {
     const Spec& s = spec();
     const int C = s.flow_dim, N = opt_.lsd_steps;
     auto r256 = [](size_t n) { return (n + 255) & ~static_cast<size_t>(255); };
@@ -966,7 +968,15 @@ void Engine::flow_scratch_layout(int rows, size_t off[5]) const {
     off[1] = off[0] + r256(static_cast<size_t>(16) * rows * C * 4);
     off[2] = off[1] + r256(static_cast<size_t>(N) * rows * C * 4);
     off[3] = off[2] + r256(static_cast<size_t>(N) * rows * model_->mod_width * 4);
-    off[4] = off[3] + r256(flow_head_workspace_bytes(rows, C, model_->flow_wtype));
+    off[4] = off[3] + r256(flow_head_workspace_bytes(rows, C, model_->flow_wtype, s.flow_blocks));
+    off[5] = off[4] + r256(flow_ring_ctl_bytes(rows, s.flow_blocks));
+}
+
+void Engine::check_flow_ring(const unsigned* ctl, int rows) {
+    if (!ctl || model_->flow_wtype != W_BF16 || spec().flow_dim != 512) return;
+    unsigned err = 0;
+    PTTS_HIP(hipMemcpy(&err, ctl + flow_ring_err_word(rows, spec().flow_blocks), 4, hipMemcpyDeviceToHost));
+    if (err) throw std::runtime_error("flow head: a hand-off between workgroups timed out (the persistent launch was not fully resident)");
 }
 
 // frame (optional): the batch whose frame bookkeeping (EOS publication, frame counter, latent filing) rides in the launches
@@ -984,7 +994,13 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
     launch_skinny_gemm(g, st);
     FramePublish pub;
     if (frame) { pub.eos = frame->eos.f(); pub.step = frame->step_dev.as<int>(); pub.h_eos_all = frame->h_eos_all; pub.h_flag = frame->h_flag; }
-    launch_flow_mod_input(flow_te_.f(), fs.cemb, cs, hd_.flow_cond_b, fs.ymod, N, B, C, st, frame ? &pub : nullptr);
+    // the persistent head's counters start every call at zero; this launch (two boundaries ahead of the head) clears them
+    FlowHeadArgs probe;
+    probe.C = C; probe.L = s.latent; probe.blocks = s.flow_blocks; probe.steps = N; probe.B = B; probe.wtype = model_->flow_wtype;
+    probe.block_wtype = model_->flow_block_wtype; probe.ring_ctl = fs.ctl; probe.ring_wg_budget = 224 / std::max(lanes_, 1);
+    const bool ring = fs.ctl && flow_ring_supported(probe);
+    launch_flow_mod_input(flow_te_.f(), fs.cemb, cs, hd_.flow_cond_b, fs.ymod, N, B, C, st, frame ? &pub : nullptr, ring ? fs.ctl : nullptr,
+                          ring ? static_cast<int>(flow_ring_ctl_bytes(B, s.flow_blocks) / 4) : 0);
     if (model_->ada_packed) {
         SkinnyArgs m;
         m.A = fs.ymod; m.lda = C; m.Wp = model_->ada_packed; m.wtype = wt; m.M = N * B; m.N = model_->mod_width; m.K = C;
@@ -1003,6 +1019,8 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
     fa.w_in = model_->flow_in_packed; fa.b_in = hd_.flow_in_b; fa.w_out = model_->flow_out_packed; fa.b_out = hd_.flow_out_b;
     fa.host_tabs = &model_->flow_tabs; fa.workspace = fs.ws; fa.wtype = model_->flow_wtype; fa.eps = s.flow_eps;
     fa.block_wtype = model_->flow_block_wtype;
+    fa.ring_ctl = ring ? fs.ctl : nullptr;
+    fa.ring_wg_budget = probe.ring_wg_budget;   // concurrent lanes share the chip: every ring in flight must be fully resident
     fa.x0_step = x0_step; fa.x0_step_stride = x0_step_stride; fa.probe_a = probe_a; fa.probe_b = probe_b;
     if (frame) {   // the counter was advanced when the EOS logits were published: the frame index is *step - 1
         fa.x0_step = frame->step_dev.as<int>(); fa.x0_step_bias = -1;

@@ -217,10 +217,12 @@ private:
     void flow_dev(Batch& b, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev, int B,
                   const int* x0_step = nullptr, long long x0_step_stride = 0, hipEvent_t probe_a = nullptr, hipEvent_t probe_b = nullptr,
                   bool frame_mode = false);   // frame_mode: EOS publication, frame counter and latent filing ride in the phase's launches
-    struct FlowScratch { float *cemb, *ymod, *mods, *ws; };
+    struct FlowScratch { float *cemb, *ymod, *mods, *ws; unsigned* ctl; };
     void flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_dev, const float* x0_dev, long long x0_stride, float* x_out_dev,
                    int B, const int* x0_step, long long x0_step_stride, hipEvent_t probe_a, hipEvent_t probe_b, Batch* frame);
-    void flow_scratch_layout(int rows, size_t off[5]) const;
+    void flow_scratch_layout(int rows, size_t off[6]) const;
+    // After the stream has drained: throws if a hand-off wait of the persistent flow head gave up during the calls since the last check.
+    void check_flow_ring(const unsigned* ctl, int rows);
     void mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs, hipStream_t st);
     void prefill_utterance(Batch& b, int slot, const Utterance& u);
     void fill_noise(std::vector<std::mt19937>& rngs, const std::vector<Utterance>& utts, int step, float* host_x0);
@@ -310,7 +312,7 @@ public:
     DevBuf dx, dh, dqkv, dq, datt, dff;  // decoder-transformer scratch (separate: the decoder overlaps the frame loop)
     TfScratch dec_scratch() const { return TfScratch{dh.f(), dqkv.f(), dq.f(), datt.f(), dff.f()}; }
     // flow scratch
-    DevBuf cemb, ymod, mods, flow_ws;
+    DevBuf cemb, ymod, mods, flow_ws, flow_ctl;
     DevBuf partial;   // split-K slabs of the decode step [splits][B][d_model] f32
     DevBuf hq, hd, attq, attd, ffq, ffd;   // int8 engine: the decode step's matrix inputs as int8 rows + block scales [K / 64][Mq]
     int q_rows = 0;                        // Mq = B rounded up to 16

@@ -346,6 +346,7 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
     bool dec_separate = false;
     for (auto& r : runs) dec_separate = dec_separate || r.b->dec_st != r.b->st;
     if (dec_separate) PTTS_HIP(hipStreamSynchronize(dec_stream_));
+    for (auto& r : runs) check_flow_ring(r.b->flow_ctl.as<unsigned>(), r.b->B);
 }
 
 void Engine::fetch_staged(Job& job, const std::vector<int>& frames, std::vector<UtteranceResult>& out, bool want_latents) {
@@ -471,6 +472,7 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
         pending = 0;
     }
     PTTS_HIP(hipStreamSynchronize(stream_));
+    check_flow_ring(b.flow_ctl.as<unsigned>(), 1);
     if (capture) {
         capture->frames = frames - pending;
         capture->latents.resize(static_cast<size_t>(frames) * L);
@@ -652,6 +654,7 @@ void Engine::op_flow_euler(const float* cond, const float* x0, int B, float* x_o
     flow_dev(b, b.cond.f(), b.x0.f(), s.latent, b.xcur.f(), B);
     PTTS_HIP(hipMemcpyAsync(x_out, b.xcur.p, static_cast<size_t>(B) * s.latent * 4, hipMemcpyDeviceToHost, stream_));
     PTTS_HIP(hipStreamSynchronize(stream_));
+    check_flow_ring(b.flow_ctl.as<unsigned>(), B);
 }
 
 void Engine::q8_linear(const float* A, int M, int K, const float* W, int N, float* out) {

@@ -877,9 +877,10 @@ static void flow_head_shape(int C, int B, bool bf, int& G, int& rpg) {
     if (const char* e = std::getenv("FLOW_HEAD_ROWS")) { const int r = std::atoi(e); if (r == 1 || r == 2 || r == 4 || r == 8 || r == 16) rpg = r; }
 }
 
-size_t flow_head_workspace_bytes(int B, int C, int wtype) {
-    (void)wtype;
-    return ((size_t)2 * B * C + (size_t)2 * kMaxFlowSplit * B * C + (size_t)2 * B * 32) * sizeof(float);   // h x2, partials x2, x x2
+size_t flow_head_workspace_bytes(int B, int C, int wtype, int blocks) {
+    const size_t chain = ((size_t)2 * B * C + (size_t)2 * kMaxFlowSplit * B * C + (size_t)2 * B * 32) * sizeof(float);   // h x2, partials x2, x x2
+    const size_t ring = (wtype == W_BF16 && C == 512) ? flow_ring_workspace_bytes(B, blocks) : 0;   // the persistent form keeps one set per block
+    return chain > ring ? chain : ring;
 }
 
 // hipFuncSetAttribute is per device and per kernel; remember where it has been applied.
@@ -984,6 +985,7 @@ static void prepare_chain() {
 }
 void flow_head_prepare(int C, int wtype) {
     const bool bf = wtype == W_BF16;
+    if (bf && C == 512) flow_ring_prepare();
     switch (C) {
         case 128: bf ? prepare_chain<__bf16, 128, true>() : prepare_chain<float, 128, false>(); break;
         case 256: bf ? prepare_chain<__bf16, 256, true>() : prepare_chain<float, 256, false>(); break;
@@ -1007,6 +1009,7 @@ void flow_head_prepare(int C, int wtype) {
 // Launches one call of launch_flow_head makes: steps * blocks block launches plus one tail launch per step, or one
 // tail launch in all where the tails ride in the next step's first block launch.
 int flow_head_launch_count(const FlowHeadArgs& a) {
+    if (flow_ring_supported(a)) return 1;
     const bool bf = a.wtype == W_BF16, q8 = a.block_wtype == W_I8;
     int G = 4, rpg = 16;
     flow_head_shape(a.C, a.B, bf, G, rpg);
@@ -1019,6 +1022,7 @@ void launch_flow_head(const FlowHeadArgs& a, hipStream_t s) {
     if (a.B <= 0) return;
     if (a.L != 32 || a.steps <= 0 || a.blocks <= 0) throw std::runtime_error("flow head: latent_dim must be 32");
     if (!a.workspace || !a.host_tabs) throw std::runtime_error("flow head: workspace and host pointer tables are required");
+    if (flow_ring_supported(a)) { launch_flow_ring(a, s); return; }
     const bool bf = a.wtype == W_BF16;
     const bool q8 = a.block_wtype == W_I8;
     int G = 4, rpg = 16;

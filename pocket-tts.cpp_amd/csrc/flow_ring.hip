@@ -1,0 +1,546 @@
+// LSD flow head as ONE persistent launch per frame: all lsd_steps Euler iterations of the adaLN MLP
+// (/root/reference/src/pocket_tts.cpp:414-451 called from the loop at :615-622) with every weight matrix held in
+// registers for the whole launch.
+//
+// flow_head.hip runs the same arithmetic as a chain of steps * blocks launches and re-reads every matrix once per
+// Euler step; a launch there costs ~3.3 us before its first useful instruction.  Here the chain's links are
+// workgroups that stay resident and hand rows to each other through L2:
+//
+//   grid = replicas x blocks x G workgroups of 256 threads (one wave per SIMD, so each wave may hold up to 512
+//   registers), one per CU.  Workgroup (rep, blk, g) owns, for residual block blk, the column slice g of fc1 and the
+//   matching K-slice of fc2 (64 KB + 64 KB of bf16 at flow_dim 512, G = 8): 128 registers per lane, loaded once.
+//   Rows travel in groups of RPG utterances; replica rep serves the row groups q = rep, rep + replicas, ...  A "visit" is one row group passing one workgroup: rebuild the residual
+//   stream from the previous block's G partial slabs, LayerNorm + adaLN modulation, fc1 slice, SiLU, fc2 K-slice,
+//   publish the partial slab.  The workgroups of block 0 also run, for the row group they are about to start, the
+//   tail of the previous Euler step (last residual update, final adaLN, output projection, x += dt * v) and the
+//   input projection, redundantly in each of the G workgroups, so a step has exactly `blocks` hand-offs.
+//
+// Hand-off (producer -> the G consumers of the next block): payload stored write-through (sc1) in whole 128-byte
+// lines, every storing wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, one lane adds 1 to the
+// (block, row group) counter with an agent-scope atomic; the consumer's lane 0 polls that counter with sc1 loads
+// until it reaches G * (visits so far), a workgroup barrier follows, then every load of handed-off bytes is an sc1
+// buffer load.  No dispatch order, co-location or cache state is assumed.  Counters only grow within a launch and are
+// zeroed by an earlier kernel of the same frame.  Every spin is bounded: a workgroup that gives up raises the error
+// word, which every other spin also watches, and the launch drains.
+//
+// Sums are formed in a fixed order (partials 0..G-1), so results are bitwise reproducible and equal to the launch
+// chain's G = 8 variant.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <mutex>
+#include <set>
+#include <stdexcept>
+
+#include "kernels.h"
+
+namespace ptts {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+
+constexpr int kThreads = 256, kWaves = 4;
+constexpr int C = 512, L = 32, G = 8;
+constexpr int KSTEP = 32, NT = C / 16, NT1 = NT / G, KS = C / KSTEP, KS2 = KS / G, CS = C / G;
+// Row pitches of the A-operand planes: 64 bytes past a multiple of 256, so that the 16 pieces (4 rows x 4 k-groups) one
+// fragment read touches fall on 16 different groups of 4 banks.
+constexpr int LDA = C + 32, LDA2 = CS + 32, LDX = L + 8;
+constexpr int NTL = L / 16, KPARTS = kWaves / NTL, KSP = KS / KPARTS;   // output projection: K split over the waves
+constexpr int kCtlStride = 32;                               // words between counters: one 128-byte line each
+constexpr unsigned kSpinLimit = 600000u;
+constexpr int kTw = 128 + 8;                                 // row pitch of the per-wave transpose buffer (floats)
+constexpr int T2 = NT / kWaves, TI = NT / kWaves;            // fc2 / input-projection tiles per wave
+static_assert(NT1 == kWaves && KS2 == 2 && KSP == 8 && NTL == 2 && T2 == 8, "flow ring: tiling written for flow_dim 512, latent 32, 8 slices, 4 waves");
+
+// v * sigmoid(v) on the hardware exp2 / reciprocal (about 1 ulp each): this form serves the bf16 engine only
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f)); }
+
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 64 lanes, the same value in every lane (four DPP steps inside each row of 16, then the four row sums)
+__device__ __forceinline__ float wsum(float v) {
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// A-operand fragment of k-step k0 / 32: only the first RPG rows of a plane are live, MFMA row r reads row r % RPG (lanes
+// that share a row read the same address, which the LDS broadcasts), so output rows >= RPG repeat live rows and are
+// never stored.
+template <int RPG>
+__device__ __forceinline__ bf16x8 afrag(const __bf16* A, int lda, int k0, int lane) {
+    return *(const bf16x8*)(A + (lane & (RPG - 1)) * lda + k0 + 8 * (lane >> 4));
+}
+// acc += (hi + lo) * fragment
+__device__ __forceinline__ void mma2(const bf16x8 hi, const bf16x8 lo, const uint4 w, f32x4& acc) {
+    const bf16x8 b8 = __builtin_bit_cast(bf16x8, w);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, b8, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, b8, acc, 0, 0, 0);
+}
+
+// Output rows repeat with period 4 (see afrag), so the four 16-lane groups of an accumulator hold the same four rows:
+// lane group q keeps row q.  One element per lane instead of four, and no lane is idle.
+__device__ __forceinline__ float own_row(const f32x4 acc, int q) { return q == 0 ? acc[0] : q == 1 ? acc[1] : q == 2 ? acc[2] : acc[3]; }
+
+__device__ __forceinline__ void put1(__bf16* A0, __bf16* A1, int idx, float v) {
+    const __bf16 hi = (__bf16)v;
+    A0[idx] = hi;
+    A1[idx] = (__bf16)(v - (float)hi);
+}
+
+__device__ __forceinline__ void put4(__bf16* A0, __bf16* A1, int idx, const float4 v) {
+    bf16x4 hi, lo;
+    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+    *(bf16x4*)(A0 + idx) = hi;
+    *(bf16x4*)(A1 + idx) = lo;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+
+// handed-off bytes: write-through stores and L1-bypassing loads (sc1), 16 bytes per lane
+__device__ __forceinline__ float4 ld_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16));
+}
+__device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, const float4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, byte_off, 0, 16);
+}
+
+// One lane waits until *cnt >= target.  false: gave up (or another workgroup did); the error word is then set.
+__device__ __forceinline__ bool ring_wait(unsigned* cnt, unsigned target, unsigned* err) {
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        if (spins >= kSpinLimit) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        if ((spins & 31u) == 31u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+}  // namespace
+
+struct FlowRingArgs {
+    const float* x0; long long x0_stride; const int* x0_step; long long x0_step_stride; int x0_step_bias;
+    float* x_out; float* latents; int max_frames;
+    const float* mods;
+    int B, blocks, steps, mod_width, replicas, ngroups;
+    const void* w_in; const float* b_in; const void* w_out; const float* b_out;
+    const void* w1[kFlowRingMaxBlocks]; const void* w2[kFlowRingMaxBlocks];
+    const float* b1[kFlowRingMaxBlocks]; const float* b2[kFlowRingMaxBlocks];
+    const float* ln_g[kFlowRingMaxBlocks]; const float* ln_b[kFlowRingMaxBlocks];
+    float* ws; unsigned ws_bytes;        // hstage [blocks][B][C] then part [blocks][G][B][C], f32
+    unsigned* ctl;                       // counters [blocks][ngroups] one per 128-byte line, then the error word
+    float eps, dt;
+    long long* stamps;                   // optional [16]: cycle counter along one mid-chain visit (tuning aid)
+};
+
+// RPG: utterance rows per row group (one wave per row in the element-wise phases).
+template <int RPG>
+__global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* hbuf = (float*)smem;                              // [RPG][C] f32: input-projection result; K-part sums of the output projection
+    __bf16* A0 = (__bf16*)(hbuf + RPG * C);                   // [2][RPG][LDA]
+    __bf16* A1 = A0 + RPG * LDA;
+    __bf16* S0 = A1 + RPG * LDA;                             // [2][RPG][LDA2]
+    __bf16* S1 = S0 + RPG * LDA2;
+    __bf16* X0 = S1 + RPG * LDA2;                            // [2][RPG][LDX]
+    __bf16* X1 = X0 + RPG * LDX;
+    float* tbuf = (float*)(X1 + RPG * LDX);                   // [waves][RPG][128] f32: per-wave transpose of the fc2 tiles
+    float* xkeep = tbuf + kWaves * RPG * kTw;                 // [local groups][RPG][L] f32: x of this workgroup's row groups (block 0)
+    int* sflag = (int*)(xkeep + ((a.ngroups + a.replicas - 1) / a.replicas) * RPG * L);
+    uint4* win_l = (uint4*)(sflag + 4);                       // block 0: input projection [NT][64 lanes] fragments, then output projection [NTL * KS][64]
+    uint4* wout_l = win_l + NT * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wg = blockIdx.x;
+    const int rep = wg / (a.blocks * G), blk = (wg / G) % a.blocks, g = wg % G;
+    const int lq = lane >> 4, ccol = lane & 15;
+    static_assert(RPG == 4, "flow ring: one accumulator row per 16-lane group");
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)a.ws_bytes, 0x00020000);
+    const size_t BC = (size_t)a.B * C;
+    unsigned* err = a.ctl + (size_t)a.blocks * a.ngroups * kCtlStride;
+    const bool first_blk = blk == 0;
+
+    // ---- this workgroup's matrices, once: fc1 tile `wave` of slice g over all of K; fc2 tiles 8 * wave .. 8 * wave + 7
+    // (128 consecutive columns: four whole 128-byte lines of every output row) for K-slice g
+    uint4 wf1[KS], wf2[T2][KS2];
+    {
+        const uint4* w1p = (const uint4*)a.w1[blk] + ((long long)(g * NT1 + wave) * KS) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf1[ks] = w1p[ks * 64];
+        const uint4* w2p = (const uint4*)a.w2[blk] + (long long)(g * KS2) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < T2; ++i) {
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) wf2[i][ks] = w2p[((long long)(T2 * wave + i) * KS + ks) * 64];
+        }
+    }
+    const float bias1 = a.b1[blk][g * CS + wave * 16 + ccol];
+    // block 0 also needs the input projection (tiles wave, wave + 4, ...) and its share of the output projection: in LDS,
+    // fragment-major as in global memory, so a wave's read of one fragment is 1 KB contiguous
+    float bin[TI];
+    const int to = wave % NTL, kpo = wave / NTL;
+    if (first_blk) {
+        for (int i = tid; i < NT * 64; i += kThreads) win_l[i] = ((const uint4*)a.w_in)[i];
+        for (int i = tid; i < NTL * KS * 64; i += kThreads) wout_l[i] = ((const uint4*)a.w_out)[i];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) bin[i] = a.b_in[(wave + kWaves * i) * 16 + ccol];
+        __syncthreads();
+    }
+    const int c0 = 4 * lane, c1 = 4 * (lane + 64);          // this lane's two float4 pieces of a row
+    // LayerNorm affine of this block and the fc2 bias of the block before it (block 0: of the last block, for the tail)
+    const int pblk = first_blk ? a.blocks - 1 : blk - 1;
+    const float4 lg0 = ld4(a.ln_g[blk] + c0), lg1 = ld4(a.ln_g[blk] + c1), lb0 = ld4(a.ln_b[blk] + c0), lb1 = ld4(a.ln_b[blk] + c1);
+    const float4 pb0 = ld4(a.b2[pblk] + c0), pb1 = ld4(a.b2[pblk] + c1);
+
+    const unsigned h_off_prev = (unsigned)((size_t)pblk * BC * 4);
+    const unsigned p_off_prev = (unsigned)(((size_t)a.blocks * BC + (size_t)pblk * G * BC) * 4);
+    const unsigned h_off_mine = (unsigned)((size_t)blk * BC * 4);
+    const unsigned p_off_mine = (unsigned)(((size_t)a.blocks * BC + ((size_t)blk * G + g) * BC) * 4);
+
+    // One pass of the tail of an Euler step for the row group (block-0 workgroups): h of the last block's output ->
+    // final adaLN -> output projection -> x += dt * v.  Leaves x in xk (LDS) and, bf16-split, in the X planes.
+    auto step_tail = [&](const float* mods_prev, int row0, int nrows, float* xk, const float* xsrc, long long xsrc_stride, bool write_out) {
+        const bool live = wave < nrows;
+        if (live) {
+            const long long grow = row0 + wave;
+            const float* mrow = mods_prev + grow * a.mod_width;
+            const float* mfin = mrow + a.blocks * 3 * C;
+            const float* gate = mrow + (a.blocks - 1) * 3 * C + 2 * C;
+            const float4 sh0 = ld4(mfin + c0), sh1 = ld4(mfin + c1), sc0 = ld4(mfin + C + c0), sc1v = ld4(mfin + C + c1);
+            const float4 gt0 = ld4(gate + c0), gt1 = ld4(gate + c1);
+            const unsigned ro = (unsigned)(grow * C * 4);
+            float4 h0 = ld_sc1(rs, h_off_prev + ro + c0 * 4), h1 = ld_sc1(rs, h_off_prev + ro + c1 * 4);
+            float4 p0[G], p1[G];
+#pragma unroll
+            for (int s = 0; s < G; ++s) {
+                p0[s] = ld_sc1(rs, p_off_prev + (unsigned)(s * BC * 4) + ro + c0 * 4);
+                p1[s] = ld_sc1(rs, p_off_prev + (unsigned)(s * BC * 4) + ro + c1 * 4);
+            }
+            float4 s0 = p0[0], s1 = p1[0];
+#pragma unroll
+            for (int s = 1; s < G; ++s) {
+                s0.x += p0[s].x; s0.y += p0[s].y; s0.z += p0[s].z; s0.w += p0[s].w;
+                s1.x += p1[s].x; s1.y += p1[s].y; s1.z += p1[s].z; s1.w += p1[s].w;
+            }
+            h0.x += gt0.x * (s0.x + pb0.x); h0.y += gt0.y * (s0.y + pb0.y); h0.z += gt0.z * (s0.z + pb0.z); h0.w += gt0.w * (s0.w + pb0.w);
+            h1.x += gt1.x * (s1.x + pb1.x); h1.y += gt1.y * (s1.y + pb1.y); h1.z += gt1.z * (s1.z + pb1.z); h1.w += gt1.w * (s1.w + pb1.w);
+            const float mean = wsum(((h0.x + h0.y) + (h0.z + h0.w)) + ((h1.x + h1.y) + (h1.z + h1.w))) * (1.0f / (float)C);
+            const float d0 = h0.x - mean, d1 = h0.y - mean, d2 = h0.z - mean, d3 = h0.w - mean;
+            const float d4 = h1.x - mean, d5 = h1.y - mean, d6 = h1.z - mean, d7 = h1.w - mean;
+            const float rstd = __builtin_amdgcn_rsqf(wsum(((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7))) * (1.0f / (float)C) + a.eps);
+            float4 y0, y1;
+            y0.x = (d0 * rstd) * (1.0f + sc0.x) + sh0.x; y0.y = (d1 * rstd) * (1.0f + sc0.y) + sh0.y;
+            y0.z = (d2 * rstd) * (1.0f + sc0.z) + sh0.z; y0.w = (d3 * rstd) * (1.0f + sc0.w) + sh0.w;
+            y1.x = (d4 * rstd) * (1.0f + sc1v.x) + sh1.x; y1.y = (d5 * rstd) * (1.0f + sc1v.y) + sh1.y;
+            y1.z = (d6 * rstd) * (1.0f + sc1v.z) + sh1.z; y1.w = (d7 * rstd) * (1.0f + sc1v.w) + sh1.w;
+            put4(A0, A1, wave * LDA + c0, y0);
+            put4(A0, A1, wave * LDA + c1, y1);
+        }
+        __syncthreads();
+        f32x4 acco = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            bf16x8 fh[KSP], fl[KSP];
+#pragma unroll
+            for (int ks = 0; ks < KSP; ++ks) { fh[ks] = afrag<RPG>(A0, LDA, (kpo * KSP + ks) * KSTEP, lane); fl[ks] = afrag<RPG>(A1, LDA, (kpo * KSP + ks) * KSTEP, lane); }
+#pragma unroll
+            for (int ks = 0; ks < KSP; ++ks) mma2(fh[ks], fl[ks], wout_l[(to * KS + kpo * KSP + ks) * 64 + lane], acco);
+        }
+        *(f32x4*)(hbuf + wave * 256 + lane * 4) = acco;
+        __syncthreads();
+        for (int i = tid; i < RPG * L; i += kThreads) {
+            const int r = i / L, c = i % L;
+            float v = 0.f;
+            if (r < nrows) {
+                const int tt = c / 16, ln = (r / 4) * 16 + (c % 16), ri = r % 4;   // accumulator of tile tt: lane ln, element ri
+                float sacc = 0.f;
+#pragma unroll
+                for (int k = 0; k < KPARTS; ++k) sacc += hbuf[(k * NTL + tt) * 256 + ln * 4 + ri];
+                const float xin = xsrc ? xsrc[(long long)(row0 + r) * xsrc_stride + c] : xk[r * L + c];
+                v = xin + (sacc + a.b_out[c]) * a.dt;
+                xk[r * L + c] = v;
+                if (write_out) {
+                    const long long row = row0 + r;
+                    a.x_out[row * L + c] = v;
+                    if (a.latents) a.latents[(row * a.max_frames + (*a.x0_step + a.x0_step_bias)) * L + c] = v;
+                }
+            }
+            put1(X0, X1, r * LDX + c, v);
+        }
+    };
+
+    const bool stamp_wg = a.stamps && rep == 0 && blk == (a.blocks > 3 ? 3 : 1) && g == 0 && tid == 0;
+#define RING_STAMP(i) do { if (stamp_wg && j == a.steps / 2 && q == rep) a.stamps[i] = __builtin_readcyclecounter(); } while (0)
+    const float* x0p = a.x0 + (a.x0_step ? (long long)(*a.x0_step + a.x0_step_bias) * a.x0_step_stride : 0);
+
+    for (int j = 0; j < a.steps; ++j) {
+        const float* mods_j = a.mods + (size_t)j * a.B * a.mod_width;
+        int qi = 0;
+        for (int q = rep; q < a.ngroups; q += a.replicas, ++qi) {
+            const int row0 = q * RPG;
+            const int nrows = (a.B - row0) < RPG ? (a.B - row0) : RPG;
+            const bool live = wave < nrows;
+            const long long grow = row0 + (live ? wave : 0);
+            // ---- operands that do not depend on the chain: this step's adaLN rows for this block (and the previous block's gate)
+            const float* mrow = mods_j + grow * a.mod_width;
+            float4 sh0, sh1, sc0, sc1v, gt0, gt1;
+            if (live) {
+                const float* mblk = mrow + blk * 3 * C;
+                sh0 = ld4(mblk + c0); sh1 = ld4(mblk + c1); sc0 = ld4(mblk + C + c0); sc1v = ld4(mblk + C + c1);
+                if (!first_blk) { gt0 = ld4(mrow + (blk - 1) * 3 * C + 2 * C + c0); gt1 = ld4(mrow + (blk - 1) * 3 * C + 2 * C + c1); }
+            }
+            RING_STAMP(0);
+            // ---- wait for the producers of this row group
+            if (!first_blk || j > 0) {
+                if (tid == 0) {
+                    unsigned* cnt = a.ctl + ((size_t)pblk * a.ngroups + q) * kCtlStride;
+                    const unsigned target = (unsigned)G * (unsigned)(first_blk ? j : j + 1);
+                    *sflag = ring_wait(cnt, target, err) ? 1 : 0;
+                    RING_STAMP(1);
+                }
+                __syncthreads();
+                if (*sflag == 0) return;
+            }
+            RING_STAMP(2);
+            float4 h0, h1;
+            if (first_blk) {
+                float* xk = xkeep + qi * RPG * L;
+                if (j > 0) {
+                    step_tail(a.mods + (size_t)(j - 1) * a.B * a.mod_width, row0, nrows, xk, j == 1 ? x0p : nullptr, a.x0_stride, false);
+                } else {
+                    for (int i = tid; i < RPG * L; i += kThreads) {
+                        const int r = i / L, c = i % L;
+                        put1(X0, X1, r * LDX + c, r < nrows ? x0p[(long long)(row0 + r) * a.x0_stride + c] : 0.f);
+                    }
+                }
+                __syncthreads();
+                // input projection: h = W_in x + b_in
+                const bf16x8 xh = afrag<RPG>(X0, LDX, 0, lane), xl = afrag<RPG>(X1, LDX, 0, lane);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma2(xh, xl, win_l[(wave + kWaves * i) * 64 + lane], acc);
+                    const int c = (wave + kWaves * i) * 16 + ccol;
+                    hbuf[lq * C + c] = own_row(acc, lq) + bin[i];
+                }
+                __syncthreads();
+                if (live) { h0 = ld4(hbuf + wave * C + c0); h1 = ld4(hbuf + wave * C + c1); }
+            } else if (live) {
+                const unsigned ro = (unsigned)(grow * C * 4);
+                h0 = ld_sc1(rs, h_off_prev + ro + c0 * 4);
+                h1 = ld_sc1(rs, h_off_prev + ro + c1 * 4);
+                float4 p0[G], p1[G];
+#pragma unroll
+                for (int s = 0; s < G; ++s) {
+                    p0[s] = ld_sc1(rs, p_off_prev + (unsigned)(s * BC * 4) + ro + c0 * 4);
+                    p1[s] = ld_sc1(rs, p_off_prev + (unsigned)(s * BC * 4) + ro + c1 * 4);
+                }
+                float4 s0 = p0[0], s1 = p1[0];
+#pragma unroll
+                for (int s = 1; s < G; ++s) {
+                    s0.x += p0[s].x; s0.y += p0[s].y; s0.z += p0[s].z; s0.w += p0[s].w;
+                    s1.x += p1[s].x; s1.y += p1[s].y; s1.z += p1[s].z; s1.w += p1[s].w;
+                }
+                h0.x += gt0.x * (s0.x + pb0.x); h0.y += gt0.y * (s0.y + pb0.y); h0.z += gt0.z * (s0.z + pb0.z); h0.w += gt0.w * (s0.w + pb0.w);
+                h1.x += gt1.x * (s1.x + pb1.x); h1.y += gt1.y * (s1.y + pb1.y); h1.z += gt1.z * (s1.z + pb1.z); h1.w += gt1.w * (s1.w + pb1.w);
+            }
+            RING_STAMP(3);
+            if (live) {
+                if (g == 0) {   // one workgroup of the block keeps the stream for the next block (whole 1 KB runs per wave)
+                    const unsigned ro = (unsigned)(grow * C * 4);
+                    st_sc1(rs, h_off_mine + ro + c0 * 4, h0);
+                    st_sc1(rs, h_off_mine + ro + c1 * 4, h1);
+                }
+                const float mean = wsum(((h0.x + h0.y) + (h0.z + h0.w)) + ((h1.x + h1.y) + (h1.z + h1.w))) * (1.0f / (float)C);
+                const float d0 = h0.x - mean, d1 = h0.y - mean, d2 = h0.z - mean, d3 = h0.w - mean;
+                const float d4 = h1.x - mean, d5 = h1.y - mean, d6 = h1.z - mean, d7 = h1.w - mean;
+                const float rstd = __builtin_amdgcn_rsqf(wsum(((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7))) * (1.0f / (float)C) + a.eps);
+                float4 y0, y1;
+                y0.x = (d0 * rstd * lg0.x + lb0.x) * (1.0f + sc0.x) + sh0.x; y0.y = (d1 * rstd * lg0.y + lb0.y) * (1.0f + sc0.y) + sh0.y;
+                y0.z = (d2 * rstd * lg0.z + lb0.z) * (1.0f + sc0.z) + sh0.z; y0.w = (d3 * rstd * lg0.w + lb0.w) * (1.0f + sc0.w) + sh0.w;
+                y1.x = (d4 * rstd * lg1.x + lb1.x) * (1.0f + sc1v.x) + sh1.x; y1.y = (d5 * rstd * lg1.y + lb1.y) * (1.0f + sc1v.y) + sh1.y;
+                y1.z = (d6 * rstd * lg1.z + lb1.z) * (1.0f + sc1v.z) + sh1.z; y1.w = (d7 * rstd * lg1.w + lb1.w) * (1.0f + sc1v.w) + sh1.w;
+                put4(A0, A1, wave * LDA + c0, y0);
+                put4(A0, A1, wave * LDA + c1, y1);
+            }
+            __syncthreads();
+            RING_STAMP(4);
+            // ---- fc1: this workgroup's 64 columns, one tile per wave over all of K
+            {
+                // groups of 4 k-steps: the fragment reads of group n + 1 are issued before the MFMAs of group n (the pins keep
+                // the compiler from sinking each read to its use, which exposes one LDS latency per MFMA pair)
+                constexpr int GK = 4, NG = KS / GK;
+                bf16x8 fh[2][GK], fl[2][GK];
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < GK; ++k) { fh[0][k] = afrag<RPG>(A0, LDA, k * KSTEP, lane); fl[0][k] = afrag<RPG>(A1, LDA, k * KSTEP, lane); }
+#pragma unroll
+                for (int n = 0; n < NG; ++n) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (n + 1 < NG) {
+#pragma unroll
+                        for (int k = 0; k < GK; ++k) {
+                            fh[(n + 1) & 1][k] = afrag<RPG>(A0, LDA, ((n + 1) * GK + k) * KSTEP, lane);
+                            fl[(n + 1) & 1][k] = afrag<RPG>(A1, LDA, ((n + 1) * GK + k) * KSTEP, lane);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < GK; ++k) mma2(fh[n & 1][k], fl[n & 1][k], wf1[n * GK + k], acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int cl = wave * 16 + ccol;
+                put1(S0, S1, lq * LDA2 + cl, silu_f(own_row(acc, lq) + bias1));
+            }
+            __syncthreads();
+            RING_STAMP(5);
+            // ---- fc2: every output column, this workgroup's K-slice -> partial slab, stored as whole lines
+            {
+                float* tw = tbuf + wave * RPG * kTw;
+                bf16x8 sh_[KS2], sl_[KS2];
+#pragma unroll
+                for (int ks = 0; ks < KS2; ++ks) { sh_[ks] = afrag<RPG>(S0, LDA2, ks * KSTEP, lane); sl_[ks] = afrag<RPG>(S1, LDA2, ks * KSTEP, lane); }
+                f32x4 acc2[T2];
+#pragma unroll
+                for (int i = 0; i < T2; ++i) {
+                    acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ++ks) mma2(sh_[ks], sl_[ks], wf2[i][ks], acc2[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < T2; ++i) tw[lq * kTw + i * 16 + ccol] = own_row(acc2[i], lq);
+                __builtin_amdgcn_wave_barrier();
+                // lane -> (row u, 16-byte chunk c of the wave's 512-byte run): 8 consecutive lanes write one whole 128-byte line
+#pragma unroll
+                for (int it = 0; it < RPG / 2; ++it) {
+                    const int u = it * 2 + (lane >> 5), c = lane & 31;
+                    const float4 v = *(const float4*)(tw + u * kTw + 4 * c);
+                    if (u < nrows) st_sc1(rs, p_off_mine + (unsigned)(((size_t)(row0 + u) * C + 128 * wave + 4 * c) * 4), v);
+                }
+            }
+            RING_STAMP(6);
+            // ---- publish: every storing wave drains, the workgroup meets, one lane signals (a signal per wave was measured
+            // slower: four times the atomics on one counter)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RING_STAMP(7);
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(a.ctl + ((size_t)blk * a.ngroups + q) * kCtlStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            RING_STAMP(8);
+        }
+    }
+    // ---- the last Euler step's tail: slice 0 of block 0 finishes each of its row groups and writes the result
+    if (first_blk && g == 0) {
+        int qi = 0;
+        for (int q = rep; q < a.ngroups; q += a.replicas, ++qi) {
+            const int row0 = q * RPG;
+            const int nrows = (a.B - row0) < RPG ? (a.B - row0) : RPG;
+            if (tid == 0) {
+                unsigned* cnt = a.ctl + ((size_t)pblk * a.ngroups + q) * kCtlStride;
+                *sflag = ring_wait(cnt, (unsigned)G * (unsigned)a.steps, err) ? 1 : 0;
+            }
+            __syncthreads();
+            if (*sflag == 0) return;
+            step_tail(a.mods + (size_t)(a.steps - 1) * a.B * a.mod_width, row0, nrows, xkeep + qi * RPG * L, a.steps == 1 ? x0p : nullptr, a.x0_stride, true);
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+
+bool flow_ring_supported(const FlowHeadArgs& a) {
+    if (std::getenv("FLOW_HEAD_NO_RING")) return false;
+    const int bw = a.block_wtype < 0 ? a.wtype : a.block_wtype;
+    return a.C == C && a.L == L && a.wtype == W_BF16 && bw == W_BF16 && a.blocks >= 2 && a.blocks <= kFlowRingMaxBlocks && a.steps >= 1 &&
+           a.ring_ctl != nullptr && a.B >= 1 && a.ring_wg_budget >= a.blocks * G;
+}
+
+// Row-group height and replica count for B rows.  More replicas shorten each workgroup's queue of row groups; the
+// chain of one row group (steps * blocks hand-offs) is the floor.  FLOW_RING_REPLICAS overrides.
+static void flow_ring_shape(int B, int blocks, int budget, int& rpg, int& replicas) {
+    rpg = 4;   // one row per wave
+    const int ngroups = (B + rpg - 1) / rpg;
+    // measured at B = 64 beside the decoder stream: 2 replicas 0.65 ms per flow phase, 3 0.49, 4 0.43 (launch chain 0.54)
+    replicas = 4;
+    if (const char* e = std::getenv("FLOW_RING_REPLICAS")) replicas = std::atoi(e);
+    const int max_rep = budget / (blocks * G);     // every workgroup must be resident at once; leave CUs for other streams
+    if (replicas > max_rep) replicas = max_rep;
+    if (replicas > ngroups) replicas = ngroups;
+    if (replicas < 1) replicas = 1;
+}
+
+size_t flow_ring_workspace_bytes(int B, int blocks) { return (size_t)blocks * (1 + G) * B * C * sizeof(float); }
+
+size_t flow_ring_ctl_bytes(int B, int blocks) {
+    const int ngroups = (B + 3) / 4;   // the smaller row-group height
+    return ((size_t)blocks * ngroups * kCtlStride + kCtlStride) * sizeof(unsigned);
+}
+
+// Word index of the error word inside the control block (non-zero after a launch: a hand-off wait gave up).
+size_t flow_ring_err_word(int B, int blocks) { return (size_t)blocks * ((B + 3) / 4) * kCtlStride; }
+
+static size_t ring_smem(int rpg, int ngroups, int replicas) {
+    const int local = (ngroups + replicas - 1) / replicas;
+    return (size_t)rpg * C * 4 + (size_t)2 * rpg * (LDA + LDA2 + LDX) * 2 + (size_t)kWaves * rpg * kTw * 4 + (size_t)local * rpg * L * 4 + 16 +
+           (size_t)(NT + NTL * KS) * 64 * 16;
+}
+
+static void ring_lds_limit(const void* kernel) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    if (done.insert({kernel, dev}).second) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+void flow_ring_prepare() {
+    ring_lds_limit((const void*)flow_ring_kernel<4>);
+}
+
+// The caller has zeroed a.ring_ctl (flow_ring_ctl_bytes) earlier on the same stream.
+void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s) {
+    if (!flow_ring_supported(a)) throw std::runtime_error("flow ring: unsupported shape");
+    if (a.x_out == a.x0) throw std::runtime_error("flow ring: x_out must not alias x0");
+    int rpg = 4, replicas = 1;
+    flow_ring_shape(a.B, a.blocks, a.ring_wg_budget, rpg, replicas);
+    FlowRingArgs r{};
+    r.x0 = a.x0; r.x0_stride = a.x0_stride; r.x0_step = a.x0_step; r.x0_step_stride = a.x0_step_stride; r.x0_step_bias = a.x0_step_bias;
+    r.x_out = a.x_out; r.latents = a.latents; r.max_frames = a.max_frames;
+    r.mods = a.mods; r.B = a.B; r.blocks = a.blocks; r.steps = a.steps; r.mod_width = a.mod_width;
+    r.replicas = replicas; r.ngroups = (a.B + rpg - 1) / rpg;
+    r.w_in = a.w_in; r.b_in = a.b_in; r.w_out = a.w_out; r.b_out = a.b_out;
+    const FlowHostTabs& t = *a.host_tabs;
+    for (int i = 0; i < a.blocks; ++i) {
+        r.w1[i] = t.w_fc1[i]; r.w2[i] = t.w_fc2[i]; r.b1[i] = t.b_fc1[i]; r.b2[i] = t.b_fc2[i]; r.ln_g[i] = t.ln_g[i]; r.ln_b[i] = t.ln_b[i];
+    }
+    r.ws = a.workspace;
+    const size_t wsb = flow_ring_workspace_bytes(a.B, a.blocks);
+    if (wsb > 0x7fffffffu) throw std::runtime_error("flow ring: workspace beyond 2 GiB");
+    r.ws_bytes = (unsigned)wsb;
+    r.ctl = a.ring_ctl;
+    r.eps = a.eps; r.dt = 1.0f / (float)a.steps;
+    r.stamps = a.cycle_probe;
+    const size_t smem = ring_smem(rpg, r.ngroups, replicas);
+    if (smem > 160 * 1024) throw std::runtime_error("flow ring: LDS request too large");
+    const int grid = replicas * a.blocks * G;
+    if (a.probe_a) (void)hipEventRecord(a.probe_a, s);
+    hipLaunchKernelGGL(flow_ring_kernel<4>, dim3(grid), dim3(kThreads), smem, s, r);
+    if (a.probe_b) (void)hipEventRecord(a.probe_b, s);
+}
+
+}  // namespace ptts

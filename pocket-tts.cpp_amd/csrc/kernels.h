@@ -147,10 +147,22 @@ struct FlowHeadArgs {
     int block_wtype = -1;         // of the residual blocks' fc1 / fc2 (-1: same as wtype; W_I8: int8 blocks)
     float eps = 1e-6f;
     long long* cycle_probe = nullptr;   // optional device [8]: cycle counter at the phase boundaries of one mid-chain block launch
+    // Control words of the persistent form (flow_ring.hip): flow_ring_ctl_bytes(B, blocks) bytes that an earlier kernel on the
+    // same stream has zeroed for this call.  Null: the launch chain is used.
+    unsigned* ring_ctl = nullptr;
+    int ring_wg_budget = 224;    // workgroups the persistent form may occupy (all must be resident at once; other rings in flight share the chip)
 };
 void launch_flow_head(const FlowHeadArgs& a, hipStream_t s);
 int flow_head_launch_count(const FlowHeadArgs& a);   // kernel launches one call makes (only C, B, steps, blocks, wtype, block_wtype are read)
-size_t flow_head_workspace_bytes(int B, int C, int wtype);
+size_t flow_head_workspace_bytes(int B, int C, int wtype, int blocks);
+// Persistent form: one launch per call, every matrix held in registers (bf16 weights, flow_dim 512, latent 32).
+constexpr int kFlowRingMaxBlocks = 8;
+bool flow_ring_supported(const FlowHeadArgs& a);
+void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s);
+size_t flow_ring_workspace_bytes(int B, int blocks);
+size_t flow_ring_ctl_bytes(int B, int blocks);
+size_t flow_ring_err_word(int B, int blocks);
+void flow_ring_prepare();   // once per device, outside stream capture
 void flow_head_prepare(int C, int wtype);   // once per device, outside stream capture
 // Host-side reorder of a flow-head weight W[N][K] into the fragment-major layout the kernel streams.
 std::vector<unsigned char> pack_flow_weight(const float* W, int N, int K, int wtype);
@@ -221,7 +233,8 @@ void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
 struct FramePublish {
     const float* eos = nullptr; int* step = nullptr; float* h_eos_all = nullptr; int* h_flag = nullptr;
 };
+// zero / zero_words (optional): words the launch also sets to zero (the control words of a later kernel of the same frame)
 void launch_flow_mod_input(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C, hipStream_t s,
-                           const FramePublish* pub = nullptr);
+                           const FramePublish* pub = nullptr, unsigned* zero = nullptr, int zero_words = 0);
 
 }  // namespace ptts

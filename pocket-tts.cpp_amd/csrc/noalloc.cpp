@@ -6,8 +6,9 @@
 // Engine::init_static_scratch asks for that address once per engine, with the engine's device current, and every
 // later use (kernel arguments) goes through the pointer it got.
 //
-// Every call on one GPU shares that GPU's array and finds the previous call's contents in it.  Nothing in it has to
-// start at zero: each area is written in full by the launch that produces it before any launch reads it.  Calls that
+// Every call on one GPU shares that GPU's array and finds the previous call's contents in it.  The only words that
+// must start a call at zero are the persistent head's counters; the call's second launch clears them before the
+// head starts.  Every other area is written in full by the launch that produces it before any launch reads it.  Calls that
 // overlap on one GPU would race on the array; a process-wide mutex per device serialises the calls made through
 // this library.
 #include <mutex>
@@ -46,19 +47,21 @@ void Engine::op_flow_euler_static(const float* cond_dev, const float* x0_dev, in
     if (B <= 0) throw std::runtime_error("flow_euler_static: rows must be positive");
     if (!cond_dev || !x0_dev || !x_out_dev || x_out_dev == x0_dev) throw std::runtime_error("flow_euler_static: three distinct device buffers are required");
     if (!static_scratch_) throw std::runtime_error("flow_euler_static: the static scratch array was not set up");
-    size_t off[5];
+    size_t off[6];
     flow_scratch_layout(B, off);
-    if (off[4] > kStaticScratchBytes)
-        throw std::runtime_error("flow_euler_static: " + std::to_string(B) + " rows need " + std::to_string(off[4]) +
+    if (off[5] > kStaticScratchBytes)
+        throw std::runtime_error("flow_euler_static: " + std::to_string(B) + " rows need " + std::to_string(off[5]) +
                                  " bytes of scratch, the static array holds " + std::to_string(kStaticScratchBytes));
     std::lock_guard<std::mutex> dev_guard(device_mutex(opt_.device));
     std::lock_guard<std::mutex> guard(mu_);
     PTTS_HIP(hipSetDevice(opt_.device));
     unsigned char* base = static_scratch_;
     FlowScratch fs{reinterpret_cast<float*>(base + off[0]), reinterpret_cast<float*>(base + off[1]),
-                   reinterpret_cast<float*>(base + off[2]), reinterpret_cast<float*>(base + off[3])};
+                   reinterpret_cast<float*>(base + off[2]), reinterpret_cast<float*>(base + off[3]),
+                   reinterpret_cast<unsigned*>(base + off[4])};
     flow_core(fs, stream_, cond_dev, x0_dev, spec().latent, x_out_dev, B, nullptr, 0, nullptr, nullptr, nullptr);
     PTTS_HIP(hipStreamSynchronize(stream_));
+    check_flow_ring(fs.ctl, B);
 }
 
 }  // namespace ptts

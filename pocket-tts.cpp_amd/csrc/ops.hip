@@ -423,8 +423,9 @@ void launch_shift_history(float* buf, long long bs, int T, int H, int C, int B, 
 // index: the index lives in device memory.  Block 0 of this launch also hands the EOS logits of the current frame to
 // the host through mapped pinned memory, raises the host-visible flag and advances the index.
 __global__ void flow_mod_input_kernel(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C,
-                                      FramePublish pub) {
+                                      FramePublish pub, unsigned* zero, int zero_words) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i * 4 < zero_words) *(uint4*)(zero + i * 4) = make_uint4(0u, 0u, 0u, 0u);   // 16 bytes a lane; zero_words is a multiple of 4
     if (i < (long long)steps * B * C) {
         int c = (int)(i % C);
         long long jb = i / C;
@@ -447,11 +448,12 @@ __global__ void flow_mod_input_kernel(const float* te, const float* cemb, int sp
     }
 }
 void launch_flow_mod_input(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C, hipStream_t s,
-                           const FramePublish* pub) {
+                           const FramePublish* pub, unsigned* zero, int zero_words) {
     long long n = (long long)steps * B * C;
     if (n <= 0) return;
+    if (zero_words % 4 || zero_words / 4 > n) throw std::runtime_error("flow_mod_input: cannot zero that many control words");
     hipLaunchKernelGGL(flow_mod_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, te, cemb, splits, bias, Y, steps, B, C,
-                       pub ? *pub : FramePublish());
+                       pub ? *pub : FramePublish(), zero, zero ? zero_words : 0);
 }
 
 }  // namespace ptts

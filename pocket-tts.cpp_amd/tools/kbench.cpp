@@ -4,10 +4,12 @@
 //                                     gemm_dec_c1_2 gemm_conv0 flow attn_decode
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -152,8 +154,50 @@ static void bench_flow(int B) {
     a.B = B; a.L = L; a.C = C; a.blocks = nb; a.steps = steps; a.mod_width = mw;
     a.w_in = packed_weight(C, L, W_T); a.b_in = (const float*)dalloc(C * 4);
     a.w_out = packed_weight(L, C, W_T); a.b_out = (const float*)dalloc(L * 4);
-    a.host_tabs = &tabs; a.workspace = (float*)dalloc(flow_head_workspace_bytes(B, C, W_T), 0); a.wtype = W_T;
+    a.host_tabs = &tabs; a.workspace = (float*)dalloc(flow_head_workspace_bytes(B, C, W_T, nb), 0); a.wtype = W_T;
     flow_head_prepare(C, W_T);
+    if (std::getenv("KB_FLOW_RING")) {
+        // persistent form against the launch chain: same inputs, outputs compared, then timed (its control words are cleared
+        // by a memset ahead of every launch here; the engine clears them in an earlier kernel of the frame)
+        const size_t ctl_bytes = flow_ring_ctl_bytes(B, nb);
+        unsigned* ctl = (unsigned*)dalloc(ctl_bytes, 0);
+        std::vector<float> ref((size_t)B * L), got((size_t)B * L);
+        setenv("FLOW_HEAD_SPLIT", "8", 1);   // the chain variant whose sums are formed in the same order
+        launch_flow_head(a, 0);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(ref.data(), a.x_out, ref.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemset(a.x_out, 0, ref.size() * 4));
+        a.ring_ctl = ctl;
+        launch_flow_head(a, 0);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got.data(), a.x_out, got.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<unsigned> hc(ctl_bytes / 4);
+        CK(hipMemcpy(hc.data(), ctl, ctl_bytes, hipMemcpyDeviceToHost));
+        double worst = 0, mag = 0;
+        size_t differ = 0;
+        for (size_t i = 0; i < ref.size(); ++i) { worst = std::max(worst, (double)std::fabs(ref[i] - got[i])); mag = std::max(mag, (double)std::fabs(ref[i])); differ += ref[i] != got[i]; }
+        std::printf("flow_ring vs chain (8 slices): max-abs diff %.3e (largest value %.3f), %zu of %zu elements differ, error word %u\n", worst, mag, differ,
+                    ref.size(), hc.back() ? 1u : hc[hc.size() - 32]);
+        if (hc[hc.size() - 32] == 0) {
+            const double usr = time_it("flow_ring", 30, [&](hipStream_t s) { CK(hipMemsetAsync(ctl, 0, ctl_bytes, s)); launch_flow_head(a, s); }, 0,
+                                       2.0 * B * steps * (2.0 * L * C + nb * 2.0 * C * C));
+            std::printf("   = %.2f us per hand-off over %d (memset included)\n", usr / (steps * nb), steps * nb);
+        }
+        {
+            long long* st = (long long*)dalloc(16 * 8, 0);
+            a.cycle_probe = st;
+            CK(hipMemset(ctl, 0, ctl_bytes));
+            launch_flow_head(a, 0);
+            CK(hipDeviceSynchronize());
+            long long h[16];
+            CK(hipMemcpy(h, st, sizeof h, hipMemcpyDeviceToHost));
+            std::printf("   visit cycles: poll %lld, barrier %lld, loads+residual %lld, norm+barrier %lld, fc1+silu+barrier %lld, fc2+stores %lld, drain %lld, barrier+signal %lld, total %lld\n",
+                        h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7], h[8] - h[0]);
+            a.cycle_probe = nullptr;
+        }
+        a.ring_ctl = nullptr;
+        unsetenv("FLOW_HEAD_SPLIT");
+    }
     const double us = time_it("flow_chain", 30, [&](hipStream_t s) { launch_flow_head(a, s); }, 0, 2.0 * B * steps * (2.0 * L * C + nb * 2.0 * C * C));
     std::printf("   = %.2f us per launch over %d launches\n", us / (steps * (nb + 1)), steps * (nb + 1));
     long long* cyc = (long long*)dalloc(64, 0);

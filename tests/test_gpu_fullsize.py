@@ -232,6 +232,33 @@ def test_int8_product_is_exact(full):
     eng.close()
 
 
+def test_flow_head_persistent_form_matches_launch_chain(full):
+    """bf16 flow head: the one-launch persistent form (every matrix in registers, workgroups handing row groups to each
+    other through L2) against the chain of per-block launches on the same inputs, and both against the oracle on the
+    bf16-rounded weights.  Row counts cover one row, ragged last row groups and more row groups than replicas."""
+    eng = full["lib"].Engine(full["path"], precision="bf16", temperature=0.0, lsd_steps=10, max_frames=F)
+    rng = np.random.default_rng(17)
+    worst_pair = worst_oracle = 0.0
+    for rows in (1, 3, 5, 64, 67):
+        cond = rng.standard_normal((rows, full["spec"].d_model)).astype(np.float32)
+        x0 = (rng.standard_normal((rows, full["spec"].latent_dim)) * 0.8).astype(np.float32)
+        ring = eng.flow_euler(cond, x0)
+        again = eng.flow_euler(cond, x0)
+        np.testing.assert_array_equal(ring, again)              # fixed summation order: reproducible bit for bit
+        os.environ["FLOW_HEAD_NO_RING"] = "1"
+        try:
+            chain = eng.flow_euler(cond, x0)
+        finally:
+            os.environ.pop("FLOW_HEAD_NO_RING", None)
+        worst_pair = max(worst_pair, float(np.abs(ring - chain).max()))
+        for i in (0, rows - 1):
+            want = full["oq"].flow_euler(cond[i], x0[i], 10)
+            worst_oracle = max(worst_oracle, float(np.abs(ring[i] - want).max()))
+    _note(f"bf16 full size flow head: persistent form vs launch chain max-abs {worst_pair:.3e}, vs oracle(bf16 weights) {worst_oracle:.3e}")
+    assert worst_pair <= 1e-4 and worst_oracle <= 2e-2
+    eng.close()
+
+
 def test_full_fp32_single_utterance_parity(full):
     """One utterance alone takes the single-row forms of the kernels (float flow head without matrix instructions,
     8 slices; prefill on the skinny kernels): flow head and whole path against the oracle, fp32 bound."""
