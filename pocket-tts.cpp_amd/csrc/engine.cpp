@@ -333,7 +333,7 @@ void Model::build_rope_tables(int lm_len, int mimi_len) {
 
 static constexpr int kDecChunk = 15;  // frames per decoder call, /root/reference/src/pocket_tts.cpp:461
 
-Batch::Batch(Engine& e, int B_) : B(B_) {
+Batch::Batch(Engine& e, int B_, bool lm_only_) : B(B_), Bw(B_), lm_only(lm_only_) {
     st = e.stream_; dec_st = e.dec_stream_; ready = e.latents_ready_;
     const Spec& s = e.spec();
     const EngineOptions& o = e.options();
@@ -342,7 +342,7 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     lm_cap = (lm_cap + 63) / 64 * 64;
     dec_cap = s.mimi_context + kDecChunk * U + 8;
     const int T0 = kDecChunk * U;
-    max_rows = std::max(std::max(B, 256), B * T0);
+    max_rows = std::max(std::max(B, 256), lm_only ? 0 : B * T0);
     // bf16 and int8 engines keep K and V in bf16 (half the cache traffic of the decode step); fp32 keeps f32
     kv16 = e.model().flow_wtype == W_BF16 && std::getenv("POCKET_TTS_KV_F32") == nullptr ? 1 : 0;
     const size_t kvb = kv16 ? 2 : 4;
@@ -350,20 +350,25 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     lm_v.alloc(static_cast<size_t>(s.lm_layers) * B * lm_cap * D * kvb);
     lm_pos.alloc(static_cast<size_t>(B) * 4);
     lm_pos_host.assign(B, 0);
-    dec_k.alloc(static_cast<size_t>(s.mimi_layers) * B * dec_cap * M * kvb);
-    dec_v.alloc(static_cast<size_t>(s.mimi_layers) * B * dec_cap * M * kvb);
+    if (!lm_only) {
+        dec_k.alloc(static_cast<size_t>(s.mimi_layers) * B * dec_cap * M * kvb);
+        dec_v.alloc(static_cast<size_t>(s.mimi_layers) * B * dec_cap * M * kvb);
+    }
     dec_pos.alloc(static_cast<size_t>(B) * 4);
+    dec_pos_host.assign(B, 0);
     const int dmax = std::max(D, M), fmax = std::max(s.lm_ffn, s.mimi_ffn);
     // transformer scratch: LM passes use at most max(B, 256) rows of width D, decoder passes B*T0 rows of width M
-    size_t rows_lm = std::max(B, 256), rows_dec = static_cast<size_t>(B) * T0;
+    size_t rows_lm = std::max(B, 256), rows_dec = lm_only ? 0 : static_cast<size_t>(B) * T0;
     size_t xe = std::max(rows_lm * D, rows_dec * M);
     x.alloc(xe * 4); h.alloc(xe * 4); q.alloc(xe * 4); att.alloc(xe * 4);
     qkv.alloc(xe * 3 * 4);
     scratch_rows_d = xe;
     scratch_rows_f = std::max(rows_lm * s.lm_ffn, rows_dec * s.mimi_ffn);
     ff.alloc(scratch_rows_f * 4);
-    dx.alloc(rows_dec * M * 4); dh.alloc(rows_dec * M * 4); dq.alloc(rows_dec * M * 4); datt.alloc(rows_dec * M * 4);
-    dqkv.alloc(rows_dec * M * 3 * 4); dff.alloc(rows_dec * s.mimi_ffn * 4);
+    if (!lm_only) {
+        dx.alloc(rows_dec * M * 4); dh.alloc(rows_dec * M * 4); dq.alloc(rows_dec * M * 4); datt.alloc(rows_dec * M * 4);
+        dqkv.alloc(rows_dec * M * 3 * 4); dff.alloc(rows_dec * s.mimi_ffn * 4);
+    }
     st_nv.alloc(static_cast<size_t>(B) * 4); st_nt.alloc(static_cast<size_t>(B) * 4); st_len.alloc(static_cast<size_t>(B) * 4);
     (void)dmax; (void)fmax;
     seq_in.alloc(static_cast<size_t>(B) * L * 4);
@@ -371,7 +376,8 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     eos.alloc(static_cast<size_t>(B) * 4);
     x0.alloc(static_cast<size_t>(B) * L * 4);
     xcur.alloc(static_cast<size_t>(B) * L * 4);
-    latents.alloc(static_cast<size_t>(B) * o.max_frames * L * 4);
+    lat_frames = (o.max_frames + 2 * kDecChunk + kDecChunk - 1) / kDecChunk * kDecChunk;
+    latents.alloc(static_cast<size_t>(B) * lat_frames * L * 4);
     ids.alloc(static_cast<size_t>(std::max(o.max_text_tokens, 1)) * 8);
     const int C = s.flow_dim;
     cemb.alloc(static_cast<size_t>(16) * B * C * 4);   // up to 16 K-slice slabs
@@ -381,6 +387,7 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
     flow_ctl.alloc(flow_ring_ctl_bytes(B, s.flow_blocks));
     PTTS_HIP(hipMemset(flow_ctl.p, 0, flow_ctl.bytes));   // the error word is read after every run, whichever form of the head ran
     // decoder activations
+    if (!lm_only) {
     zbuf.alloc(static_cast<size_t>(B) * kDecChunk * L * 4);
     qbuf.alloc(static_cast<size_t>(B) * (1 + kDecChunk) * M * 4);
     ybuf.alloc(static_cast<size_t>(B) * (s.kernel - 1 + T0) * M * 4);
@@ -398,9 +405,10 @@ Batch::Batch(Engine& e, int B_) : B(B_) {
         c = co;
     }
     audio.alloc(static_cast<size_t>(B) * kDecChunk * s.frame_size() * 4);
+    }
     PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_eos), static_cast<size_t>(B) * 4));
     PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_x0), static_cast<size_t>(3) * B * L * 4));   // BOS rows + two sets of start points
-    PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_eos_all), static_cast<size_t>(o.max_frames) * B * 4, hipHostMallocMapped));
+    PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_eos_all), static_cast<size_t>(std::max(o.max_frames, 16)) * B * 4, hipHostMallocMapped));
     PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_flag), 64, hipHostMallocMapped));
     *h_flag = 0;
     step_dev.alloc(64);
@@ -437,9 +445,10 @@ void Batch::ensure_rows(size_t rows, int d, int ffn) {
 }
 
 void Batch::drop_graphs() {
-    for (auto& ex : frame_exec)
-        if (ex) { (void)hipGraphExecDestroy(ex); ex = nullptr; }
-    graph_x0 = nullptr; graph_x0_stride = -1;
+    for (auto& kv : frame_graphs)
+        for (auto& ex : kv.second.exec)
+            if (ex) (void)hipGraphExecDestroy(ex);
+    frame_graphs.clear();
 }
 
 Batch::~Batch() {
@@ -458,9 +467,10 @@ void Batch::reset(hipStream_t s) {
     PTTS_HIP(hipMemsetAsync(lm_pos.p, 0, lm_pos.bytes, s));
     PTTS_HIP(hipMemsetAsync(dec_pos.p, 0, dec_pos.bytes, s));
     std::fill(lm_pos_host.begin(), lm_pos_host.end(), 0);
-    dec_pos_host = 0;
-    for (DevBuf* b : {&qbuf, &ybuf, &e0buf, &uebuf[0], &uebuf[1], &uebuf[2], &ebuf[0], &ebuf[1], &ebuf[2]})
-        PTTS_HIP(hipMemsetAsync(b->p, 0, b->bytes, s));
+    std::fill(dec_pos_host.begin(), dec_pos_host.end(), 0);
+    if (!lm_only)
+        for (DevBuf* b : {&qbuf, &ybuf, &e0buf, &uebuf[0], &uebuf[1], &uebuf[2], &ebuf[0], &ebuf[1], &ebuf[2]})
+            PTTS_HIP(hipMemsetAsync(b->p, 0, b->bytes, s));
     PTTS_HIP(hipMemsetAsync(x0.p, 0, x0.bytes, s));
 }
 
@@ -858,7 +868,7 @@ void Engine::lm_rows_skinny(Batch& b, int slot0, int nb, int rpb, float* X) {
 // next layer's normalised input, or after the last layer the conditioning vector and the EOS logit).
 void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float* eos_dev, bool prepped) {
     const Spec& s = spec();
-    const int B = b.B, D = s.d_model, F = s.lm_ffn;
+    const int B = b.Bw, D = s.d_model, F = s.lm_ffn;   // rows launched; b.B stays the slot stride of the caches
     const int wt = model_->lm_wtype, kstep = wt == W_I8 ? 64 : wt == W_BF16 ? 32 : 16;
     const float* seq_rows = seq_dev;
     if (!prepped) {
@@ -893,7 +903,7 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         if (proj_in_norm) { a0.seq = seq_rows; a0.w_in = win.p; a0.w_in_type = win.wtype; a0.L = s.latent; }
         launch_add_norm(a0, b.st);
     }
-    const long long layer_stride = static_cast<long long>(B) * b.lm_cap * D;
+    const long long layer_stride = static_cast<long long>(b.B) * b.lm_cap * D;
     for (int l = 0; l < s.lm_layers; ++l) {
         const TfLayer& w = hd_.lm[l];
         const Model::PackedLayer& pw = model_->lm_packed[l];
@@ -945,7 +955,7 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
 
 // Host mirror of the positions one decode step consumes; call once per step actually run.
 void Engine::lm_bookkeeping(Batch& b) {
-    for (int i = 0; i < b.B; ++i) {
+    for (int i = 0; i < b.Bw; ++i) {
         if (b.lm_pos_host[i] + 1 > b.lm_cap) throw std::runtime_error("LM context exceeds the KV-cache capacity (voice + text + frames too long)");
         b.lm_pos_host[i] += 1;
     }
@@ -993,7 +1003,10 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
     g.splits = cs; g.P = fs.cemb;
     launch_skinny_gemm(g, st);
     FramePublish pub;
-    if (frame) { pub.eos = frame->eos.f(); pub.step = frame->step_dev.as<int>(); pub.h_eos_all = frame->h_eos_all; pub.h_flag = frame->h_flag; }
+    if (frame) {
+        pub.eos = frame->eos.f(); pub.step = frame->step_dev.as<int>(); pub.h_eos_all = frame->h_eos_all; pub.h_flag = frame->h_flag;
+        pub.ring = frame->eos_ring; pub.stride = frame->B;
+    }
     // the persistent head's counters start every call at zero; this launch (two boundaries ahead of the head) clears them
     FlowHeadArgs probe;
     probe.C = C; probe.L = s.latent; probe.blocks = s.flow_blocks; probe.steps = N; probe.B = B; probe.wtype = model_->flow_wtype;
@@ -1024,7 +1037,7 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
     fa.x0_step = x0_step; fa.x0_step_stride = x0_step_stride; fa.probe_a = probe_a; fa.probe_b = probe_b;
     if (frame) {   // the counter was advanced when the EOS logits were published: the frame index is *step - 1
         fa.x0_step = frame->step_dev.as<int>(); fa.x0_step_bias = -1;
-        fa.latents = frame->latents.f(); fa.max_frames = opt_.max_frames;
+        fa.latents = frame->latents.f(); fa.max_frames = frame->lat_frames; fa.step_ring = frame->step_ring;
     }
     launch_flow_head(fa, st);
     check_launches("the flow phase");
@@ -1032,39 +1045,52 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
 
 // latent rows (batched mapping: utterance b at lat_dev + b*lat_bs, n rows of `latent` floats)
 // -> audio[b][n*frame]   (src/pocket_tts.cpp:454-546 for one chunk of n <= 15 frames)
-void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs, hipStream_t st) {
+void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs, hipStream_t st,
+                             int slot0, int nb, int ring_start) {
     const Spec& s = spec();
     if (n <= 0 || n > kDecChunk) throw std::runtime_error("decoder chunk must hold 1..15 frames");
-    const int B = b.B, L = s.latent, M = s.mimi_dim, U = s.upsample;
+    if (nb < 0) nb = b.B - slot0;
+    if (slot0 < 0 || nb <= 0 || slot0 + nb > b.B || b.lm_only) throw std::runtime_error("decoder chunk: slot range out of bounds");
+    const int B = nb, L = s.latent, M = s.mimi_dim, U = s.upsample;
     const int T0 = n * U, T0max = kDecChunk * U;
-    if (b.dec_pos_host + T0 > model_->mimi_tab_len) throw std::runtime_error("decoder position exceeds the rotary table");
+    for (int i = slot0; i < slot0 + nb; ++i)
+        if (b.dec_pos_host[i] + T0 > model_->mimi_tab_len) throw std::runtime_error("decoder position exceeds the rotary table");
     phase_begin(2, st);
-    // gather the chunk's latent rows and de-normalise them
-    PTTS_HIP(hipMemcpy2DAsync(b.zbuf.p, static_cast<size_t>(n) * L * 4, lat_dev, static_cast<size_t>(lat_bs) * 4,
-                              static_cast<size_t>(n) * L * 4, B, hipMemcpyDeviceToDevice, st));
-    launch_prep_latent(b.zbuf.f(), b.zbuf.f(), B * n, L, 1, hd_.emb_std, hd_.emb_mean, st);
+    // the chunk's latent rows, de-normalised
+    if (ring_start >= 0) {
+        launch_gather_latents(b.latents.f(), b.lat_frames, slot0, B, ring_start, n, L, hd_.emb_std, hd_.emb_mean, b.zbuf.f(), st);
+    } else {
+        PTTS_HIP(hipMemcpy2DAsync(b.zbuf.p, static_cast<size_t>(n) * L * 4, lat_dev, static_cast<size_t>(lat_bs) * 4,
+                                  static_cast<size_t>(n) * L * 4, B, hipMemcpyDeviceToDevice, st));
+        launch_prep_latent(b.zbuf.f(), b.zbuf.f(), B * n, L, 1, hd_.emb_std, hd_.emb_mean, st);
+    }
+    // state buffers of the range start at slot0; scratch buffers are used from their beginning
+    const long long qbs = static_cast<long long>(1 + kDecChunk) * M;
+    float* qbuf0 = b.qbuf.f() + slot0 * qbs;
     const DevWeight& wi = hd_.dec_in;
     GemmArgs g;
     g.A = b.zbuf.f(); g.lda = L; g.W = wi.p; g.wtype = wi.wtype; g.M = B * n; g.N = M; g.K = L; g.rpb = n;
     g.a_bs = static_cast<long long>(n) * L;
-    g.C = b.qbuf.f() + M; g.c_bs = static_cast<long long>(1 + kDecChunk) * M; g.ldc = M;
+    g.C = qbuf0 + M; g.c_bs = qbs; g.ldc = M;
     launch_gemm(g, st);
-    launch_upsample_dw(b.qbuf.f(), static_cast<long long>(1 + kDecChunk) * M, n, M, U, hd_.dec_up_w, b.dx.f(), B, st);
+    launch_upsample_dw(qbuf0, qbs, n, M, U, hd_.dec_up_w, b.dx.f(), B, st);
     const int H0 = s.kernel - 1;
     const auto& layers = hd_.dec;
     const long long ybs = static_cast<long long>(H0 + T0max) * M;
-    transformer(layers, b.dec_k.p, b.dec_v.p, b.kv16, static_cast<long long>(B) * b.dec_cap * M, b.dec_cap, b.dec_pos.as<int>(), 0, B, T0,
+    float* ybuf0 = b.ybuf.f() + slot0 * ybs;
+    transformer(layers, b.dec_k.p, b.dec_v.p, b.kv16, static_cast<long long>(b.B) * b.dec_cap * M, b.dec_cap, b.dec_pos.as<int>() + slot0, slot0, B, T0,
                 b.dx.f(), M, s.mimi_heads, s.mimi_ffn, s.mimi_eps, s.mimi_context, model_->mimi_cos, model_->mimi_sin,
-                model_->mimi_tab_len, b.dec_scratch(), b.ybuf.f() + static_cast<long long>(H0) * M, ybs, M, st, false,
+                model_->mimi_tab_len, b.dec_scratch(), ybuf0 + static_cast<long long>(H0) * M, ybs, M, st, false,
                 std::getenv("POCKET_TTS_DECODER_F32_ROWS") == nullptr);
     // SEANet decoder
     int c = 8 * s.n_filters;
+    float* e0buf0 = b.e0buf.f() + slot0 * static_cast<long long>(1 + T0max) * c;
     {
         const DevWeight& w = hd_.dec_conv0;
         GemmArgs a;
-        a.A = b.ybuf.f(); a.a_bs = ybs; a.lda = M; a.rpb = T0; a.W = w.p; a.wtype = w.wtype; a.bias = hd_.dec_conv0_b;
+        a.A = ybuf0; a.a_bs = ybs; a.lda = M; a.rpb = T0; a.W = w.p; a.wtype = w.wtype; a.bias = hd_.dec_conv0_b;
         a.M = B * T0; a.N = c; a.K = s.kernel * M;
-        a.C = b.e0buf.f() + c; a.c_bs = static_cast<long long>(1 + T0max) * c; a.ldc = c; a.c_act = ACT_ELU;
+        a.C = e0buf0 + c; a.c_bs = static_cast<long long>(1 + T0max) * c; a.ldc = c; a.c_act = ACT_ELU;
         if (B == 1 && T0 <= 256 && w.frag && !std::getenv("POCKET_TTS_NO_THIN_PASS")) {
             SkinnyArgs k;   // 80 rows against K = 7 * 512: 16 workgroups as a tiled GEMM
             k.A = a.A; k.lda = a.lda; k.Wp = w.frag; k.wtype = w.wtype; k.M = T0; k.N = c; k.K = a.K; k.bias = a.bias; k.act = ACT_ELU;
@@ -1074,7 +1100,7 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
             launch_gemm(a, st);
         }
     }
-    const float* prev = b.e0buf.f();
+    const float* prev = e0buf0;
     long long prev_bs = static_cast<long long>(1 + T0max) * c;
     int prev_bf16 = 0;   // the rows of a fused stage are bf16 in memory
     int T = T0, Tmax = T0max;
@@ -1088,26 +1114,29 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
         if (dec_fused_[i]) {
             // fused residual unit: the up-sampled rows are kept raw (bf16), behind the stream's two previous rows, in
             // the buffer that otherwise holds their ELU; one kernel does ELU -> conv -> ELU -> conv -> + skip -> ELU
-            __bf16* ybuf = reinterpret_cast<__bf16*>(b.uebuf[i].p);
-            up.C = reinterpret_cast<float*>(ybuf + static_cast<long long>(rk - 1) * co); up.c_bf16 = 1;
             up.c_bs = static_cast<long long>(rk - 1 + T2max) * co; up.ldc = r * co;
+            __bf16* ybuf = reinterpret_cast<__bf16*>(b.uebuf[i].p) + slot0 * up.c_bs;
+            up.C = reinterpret_cast<float*>(ybuf + static_cast<long long>(rk - 1) * co); up.c_bf16 = 1;
             launch_gemm(up, st);
             ResblockArgs rb;
             rb.Y = ybuf; rb.y_bs = up.c_bs;
-            rb.E = b.ebuf[i].p; rb.e_bs = static_cast<long long>(hn + T2max) * co; rb.e_off = hn;
+            rb.e_bs = static_cast<long long>(hn + T2max) * co; rb.e_off = hn;
+            rb.E = reinterpret_cast<__bf16*>(b.ebuf[i].p) + slot0 * rb.e_bs;
             rb.W1 = w1.p; rb.b1 = hd_.dec_c1_b[i]; rb.W2 = w2.p; rb.b2 = hd_.dec_c2_b[i];
             rb.T = T2; rb.B = B; rb.co = co;
             launch_resblock(rb, st);
-            prev = b.ebuf[i].f(); prev_bs = rb.e_bs; prev_bf16 = 1;
+            prev = reinterpret_cast<const float*>(rb.E); prev_bs = rb.e_bs; prev_bf16 = 1;
             c = co; T = T2; Tmax = T2max;
             continue;
         }
         up.C = b.ubuf[i].f(); up.c_bs = static_cast<long long>(T2max) * co; up.ldc = r * co;
-        up.C2 = b.uebuf[i].f() + static_cast<long long>(rk - 1) * co; up.c2_bs = static_cast<long long>(rk - 1 + T2max) * co;
+        up.c2_bs = static_cast<long long>(rk - 1 + T2max) * co;
+        float* ue0 = b.uebuf[i].f() + slot0 * up.c2_bs;
+        up.C2 = ue0 + static_cast<long long>(rk - 1) * co;
         up.ldc2 = r * co; up.c2_act = ACT_ELU;
         launch_gemm(up, st);
         GemmArgs c1;
-        c1.A = b.uebuf[i].f(); c1.a_bs = up.c2_bs; c1.lda = co; c1.rpb = T2; c1.W = w1.p; c1.wtype = w1.wtype;
+        c1.A = ue0; c1.a_bs = up.c2_bs; c1.lda = co; c1.rpb = T2; c1.W = w1.p; c1.wtype = w1.wtype;
         c1.bias = hd_.dec_c1_b[i]; c1.M = B * T2; c1.N = co / 2; c1.K = rk * co;
         c1.C = b.h1buf[i].f(); c1.c_bs = static_cast<long long>(T2max) * (co / 2); c1.ldc = co / 2; c1.c_act = ACT_ELU;
         launch_gemm(c1, st);
@@ -1115,30 +1144,33 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
         c2.A = b.h1buf[i].f(); c2.a_bs = c1.c_bs; c2.lda = co / 2; c2.rpb = T2; c2.W = w2.p; c2.wtype = w2.wtype;
         c2.bias = hd_.dec_c2_b[i]; c2.M = B * T2; c2.N = co; c2.K = co / 2;
         c2.R = b.ubuf[i].f(); c2.r_bs = up.c_bs; c2.ldr = co;
-        c2.C = b.ebuf[i].f() + static_cast<long long>(hn) * co; c2.c_bs = static_cast<long long>(hn + T2max) * co; c2.ldc = co;
+        c2.c_bs = static_cast<long long>(hn + T2max) * co; c2.ldc = co;
+        float* e0 = b.ebuf[i].f() + slot0 * c2.c_bs;
+        c2.C = e0 + static_cast<long long>(hn) * co;
         c2.c_act = ACT_ELU;
         launch_gemm(c2, st);
-        prev = b.ebuf[i].f(); prev_bs = c2.c_bs; prev_bf16 = 0;
+        prev = e0; prev_bs = c2.c_bs; prev_bf16 = 0;
         c = co; T = T2; Tmax = T2max;
     }
     launch_conv_to_mono(prev, prev_bf16, prev_bs, T, s.last_kernel * c, c, hd_.dec_final_w, hd_.dec_final_b, audio_dev, audio_bs, B, st);
     // carry the streaming histories and positions to the next chunk
-    launch_shift_history(b.qbuf.f(), static_cast<long long>(1 + kDecChunk) * M, n, 1, M, B, st);
-    launch_shift_history(b.ybuf.f(), ybs, T0, H0, M, B, st);
+    launch_shift_history(qbuf0, qbs, n, 1, M, B, st);
+    launch_shift_history(ybuf0, ybs, T0, H0, M, B, st);
     c = 8 * s.n_filters;
-    launch_shift_history(b.e0buf.f(), static_cast<long long>(1 + T0max) * c, T0, 1, c, B, st);
+    launch_shift_history(e0buf0, static_cast<long long>(1 + T0max) * c, T0, 1, c, B, st);
     T = T0; Tmax = T0max;
     for (int i = 0; i < 3; ++i) {
         const int co = c / 2, rk = s.res_kernel, hn = i < 2 ? 1 : s.last_kernel - 1;
         T *= s.ratios[i]; Tmax *= s.ratios[i];
         // bf16 rows of a fused stage: the same bytes seen as co/2 floats per row
         const int div = dec_fused_[i] ? 2 : 1;
-        launch_shift_history(b.uebuf[i].f(), static_cast<long long>(rk - 1 + Tmax) * co / div, T, rk - 1, co / div, B, st);
-        launch_shift_history(b.ebuf[i].f(), static_cast<long long>(hn + Tmax) * co / div, T, hn, co / div, B, st);
+        const long long ubs = static_cast<long long>(rk - 1 + Tmax) * co / div, ebs = static_cast<long long>(hn + Tmax) * co / div;
+        launch_shift_history(b.uebuf[i].f() + slot0 * ubs, ubs, T, rk - 1, co / div, B, st);
+        launch_shift_history(b.ebuf[i].f() + slot0 * ebs, ebs, T, hn, co / div, B, st);
         c = co;
     }
-    launch_advance_pos(b.dec_pos.as<int>(), B, T0, st);
-    b.dec_pos_host += T0;
+    launch_advance_pos(b.dec_pos.as<int>() + slot0, B, T0, st);
+    for (int i = slot0; i < slot0 + nb; ++i) b.dec_pos_host[i] += T0;
     phase_end(2, st);
     check_launches("the decoder chunk");
 }

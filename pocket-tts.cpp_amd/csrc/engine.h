@@ -208,7 +208,7 @@ private:
     // One frame of the autoregressive loop for a staged batch, free of host-side frame state (replayable as a graph):
     // LM step -> EOS logits to the host -> flow head from the start points of frame *step -> latent filed under *step.
     void frame_body(Batch& b, int parity);
-    void ensure_frame_graph(Batch& b);
+    hipGraphExec_t* ensure_frame_graph(Batch& b);
     void lm_bookkeeping(Batch& b);
     void lm_rows_skinny(Batch& b, int slot0, int nb, int rpb, float* X);
     void lm_rows(Batch& b, int slot0, int nb, int rpb, float* X, const int* adv_dev = nullptr, const int* adv_host = nullptr);
@@ -223,7 +223,10 @@ private:
     void flow_scratch_layout(int rows, size_t off[6]) const;
     // After the stream has drained: throws if a hand-off wait of the persistent flow head gave up during the calls since the last check.
     void check_flow_ring(const unsigned* ctl, int rows);
-    void mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs, hipStream_t st);
+    // slot0 / nb: the contiguous range of slots the chunk is decoded for (nb < 0: all).  ring_start >= 0: the latent rows come from
+    // the batch's latent rings starting at that ring index instead of lat_dev.
+    void mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs, hipStream_t st,
+                         int slot0 = 0, int nb = -1, int ring_start = -1);
     void prefill_utterance(Batch& b, int slot, const Utterance& u);
     void fill_noise(std::vector<std::mt19937>& rngs, const std::vector<Utterance>& utts, int step, float* host_x0);
     Batch* acquire_batch(int B, int lane = 0);
@@ -279,10 +282,17 @@ private:
 // Recurrent state and scratch of B lock-step utterances on one GPU.
 class Batch {
 public:
-    Batch(Engine& e, int B);
+    // lm_only: a staging batch for prefill passes (LM state and transformer scratch only)
+    Batch(Engine& e, int B, bool lm_only = false);
     void reset(hipStream_t s);
 
-    int B;
+    int B;            // capacity: slots, and the slot stride of every state buffer
+    int Bw;           // rows the frame step and the flow phase are launched over (<= B; the slot table narrows it to its occupied prefix)
+    bool lm_only = false;
+    // Slot-table mode (scheduler.cpp): latents and start points are rings of step_ring frames indexed by the table's global
+    // step, the EOS rows in mapped host memory a ring of eos_ring steps.  0: indexed by the frame number of one run.
+    int step_ring = 0, eos_ring = 0;
+    int lat_frames = 0;   // frames per slot of `latents` (max_frames rounded up to whole decoder chunks, plus two)
     hipStream_t st = nullptr;       // frame-loop stream of this batch
     hipStream_t dec_st = nullptr;   // decoder stream (may equal st)
     hipEvent_t ready = nullptr;     // latents of a chunk are complete (st -> dec_st)
@@ -297,7 +307,7 @@ public:
     // decoder state
     DevBuf dec_k, dec_v;    // [layers][B][dec_cap][mimi_dim]
     DevBuf dec_pos;         // int[B]
-    long long dec_pos_host = 0;
+    std::vector<long long> dec_pos_host;   // per slot
     // decoder activation buffers (history rows in front), see engine.cpp for the layout table
     DevBuf zbuf, qbuf, ybuf, e0buf, ubuf[3], uebuf[3], h1buf[3], ebuf[3];
     // transformer scratch (grown on demand by ensure_rows)
@@ -333,8 +343,9 @@ public:
     int* h_flag = nullptr;           // number of frames whose EOS logits have arrived
     const float* x0_src = nullptr;   // start points of the staged batch and their strides
     long long x0_stride = 0, x0_step_stride = 0;
-    hipGraphExec_t frame_exec[2] = {nullptr, nullptr};   // one per frame parity (each has its own timing events)
-    const float* graph_x0 = nullptr; long long graph_x0_stride = -1; bool graph_timed = false;
+    // captured frame graphs by launch width, one per frame parity (each has its own timing events)
+    struct FrameGraphs { hipGraphExec_t exec[2] = {nullptr, nullptr}; const float* x0 = nullptr; long long x0_stride = -1; bool timed = false; int ring = 0; };
+    std::map<int, FrameGraphs> frame_graphs;
     hipEvent_t tev[2][8] = {};       // lm begin/end, flow begin, probe begin/end, flow end, and an empty back-to-back pair
     ~Batch();
 };

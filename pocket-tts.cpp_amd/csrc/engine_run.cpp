@@ -161,7 +161,7 @@ void Engine::frame_body(Batch& b, int parity) {
     if (ev) { PTTS_HIP(hipEventRecord(ev[1], st)); PTTS_HIP(hipEventRecord(ev[2], st)); }
     // flow phase (:606-622); its second launch also publishes the EOS logits and advances the frame counter, its last
     // launch files the new latent under the frame index
-    flow_dev(b, b.cond.f(), b.x0_src, b.x0_stride, b.xcur.f(), b.B, b.step_dev.as<int>(), b.x0_step_stride, ev ? ev[3] : nullptr,
+    flow_dev(b, b.cond.f(), b.x0_src, b.x0_stride, b.xcur.f(), b.Bw, b.step_dev.as<int>(), b.x0_step_stride, ev ? ev[3] : nullptr,
              ev ? ev[4] : nullptr, true);
     if (ev) {
         PTTS_HIP(hipEventRecord(ev[5], st));
@@ -170,10 +170,12 @@ void Engine::frame_body(Batch& b, int parity) {
     }
 }
 
-// (Re)captures the frame graphs of a batch when its start-point source or the timing mode changed.
-void Engine::ensure_frame_graph(Batch& b) {
-    if (b.frame_exec[0] && b.graph_x0 == b.x0_src && b.graph_x0_stride == b.x0_stride && b.graph_timed == timing_) return;
-    for (auto& ex : b.frame_exec)
+// The frame graphs of a batch at its current launch width, (re)captured when the start-point source, the ring mode or the
+// timing mode changed.  Returns the two executables (one per frame parity).
+hipGraphExec_t* Engine::ensure_frame_graph(Batch& b) {
+    Batch::FrameGraphs& fg = b.frame_graphs[b.Bw];
+    if (fg.exec[0] && fg.x0 == b.x0_src && fg.x0_stride == b.x0_stride && fg.timed == timing_ && fg.ring == b.step_ring) return fg.exec;
+    for (auto& ex : fg.exec)
         if (ex) { PTTS_HIP(hipGraphExecDestroy(ex)); ex = nullptr; }
     for (int parity = 0; parity < 2; ++parity) {
         hipGraph_t g = nullptr;
@@ -186,10 +188,11 @@ void Engine::ensure_frame_graph(Batch& b) {
             throw;
         }
         PTTS_HIP(hipStreamEndCapture(b.st, &g));
-        PTTS_HIP(hipGraphInstantiate(&b.frame_exec[parity], g, nullptr, nullptr, 0));
+        PTTS_HIP(hipGraphInstantiate(&fg.exec[parity], g, nullptr, nullptr, 0));
         PTTS_HIP(hipGraphDestroy(g));
     }
-    b.graph_x0 = b.x0_src; b.graph_x0_stride = b.x0_stride; b.graph_timed = timing_;
+    fg.x0 = b.x0_src; fg.x0_stride = b.x0_stride; fg.timed = timing_; fg.ring = b.step_ring;
+    return fg.exec;
 }
 
 // Prefill, frame loop and chunked decode for a staged batch; audio stays in HBM (audio_all of every part).
@@ -208,6 +211,7 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
     struct PartRun {
         Batch* b; int first; std::vector<int> len, eos_step; std::vector<char> done;
         int n_done = 0, decoded = 0, step = 0, executed = 0, timed = 0; bool launched = false, finished = false;
+        hipGraphExec_t* exec = nullptr;
     };
     std::vector<PartRun> runs(job.parts.size());
     for (size_t p = 0; p < runs.size(); ++p) {
@@ -217,6 +221,7 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
         const int B = b.B;
         hipStream_t st = b.st;
         b.reset(st);
+        b.Bw = B; b.step_ring = 0; b.eos_ring = 0;
         PTTS_HIP(hipMemsetAsync(b.step_dev.p, 0, 4, st));
         *b.h_flag = 0;
         // Prefill.  The reference feeds the voice rows and then the text rows of an utterance as two causal passes
@@ -250,7 +255,7 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
     if (graph)
         for (auto& r : runs) {
             const std::vector<int> keep = r.b->lm_pos_host;
-            ensure_frame_graph(*r.b);
+            r.exec = ensure_frame_graph(*r.b);
             r.b->lm_pos_host = keep;
         }
 
@@ -260,7 +265,7 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
             PTTS_HIP(hipEventRecord(b.ready, b.st));
             PTTS_HIP(hipStreamWaitEvent(b.dec_st, b.ready, 0));
         }
-        mimi_decode_dev(b, b.latents.f() + static_cast<size_t>(f0) * L, static_cast<long long>(opt_.max_frames) * L, n,
+        mimi_decode_dev(b, b.latents.f() + static_cast<size_t>(f0) * L, static_cast<long long>(b.lat_frames) * L, n,
                         b.audio_all.f() + static_cast<size_t>(f0) * fs, static_cast<long long>(opt_.max_frames) * fs, b.dec_st);
     };
     auto collect_timing = [&](Batch& b, int parity) {
@@ -286,7 +291,7 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
             if (r.finished || r.launched) continue;
             Batch& b = *r.b;
             lm_bookkeeping(b);
-            if (graph) PTTS_HIP(hipGraphLaunch(b.frame_exec[r.step & 1], b.st));
+            if (graph) PTTS_HIP(hipGraphLaunch(r.exec[r.step & 1], b.st));
             else frame_body(b, r.step & 1);
             r.launched = true;
         }
@@ -331,7 +336,7 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
                 }
                 for (int f0 = r.decoded; f0 < fmax; f0 += kDecChunk) {
                     const int n = std::min(kDecChunk, fmax - f0);
-                    mimi_decode_dev(b, b.latents.f() + static_cast<size_t>(f0) * L, static_cast<long long>(opt_.max_frames) * L, n,
+                    mimi_decode_dev(b, b.latents.f() + static_cast<size_t>(f0) * L, static_cast<long long>(b.lat_frames) * L, n,
                                     b.audio_all.f() + static_cast<size_t>(f0) * fs, static_cast<long long>(opt_.max_frames) * fs, b.st);
                 }
                 r.finished = true;
@@ -367,7 +372,7 @@ void Engine::fetch_staged(Job& job, const std::vector<int>& frames, std::vector<
             if (want_latents) {
                 out[i].latents.resize(static_cast<size_t>(frames[i]) * L);
                 if (frames[i])
-                    PTTS_HIP(hipMemcpyAsync(out[i].latents.data(), b.latents.f() + static_cast<size_t>(j) * opt_.max_frames * L,
+                    PTTS_HIP(hipMemcpyAsync(out[i].latents.data(), b.latents.f() + static_cast<size_t>(j) * b.lat_frames * L,
                                             out[i].latents.size() * 4, hipMemcpyDeviceToHost, b.st));
             }
         }
@@ -399,6 +404,7 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
     const Spec& s = spec();
     const int L = s.latent, fs = s.frame_size();
     Batch& b = *acquire_batch(1);
+    b.Bw = 1; b.step_ring = 0; b.eos_ring = 0;
     prefill_utterance(b, 0, utt);
     std::vector<Utterance> one{utt};
     std::vector<std::mt19937> rngs;
@@ -415,9 +421,10 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
     b.x0_src = b.x0.f(); b.x0_stride = L; b.x0_step_stride = 0;   // start points arrive frame by frame
     if (!any_noise) PTTS_HIP(hipMemsetAsync(b.x0.p, 0, static_cast<size_t>(L) * 4, st));
     const bool graph = use_graph_ && !timing_;
+    hipGraphExec_t* exec = nullptr;
     if (graph) {
         const std::vector<int> keep = b.lm_pos_host;
-        ensure_frame_graph(b);
+        exec = ensure_frame_graph(b);
         b.lm_pos_host = keep;
     }
 
@@ -426,7 +433,7 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
         chunk_audio.resize(static_cast<size_t>(count) * fs);
         for (int f0 = 0; f0 < count; f0 += kDecChunk) {  // sub-chunks of <= 15 frames (:796)
             const int n = std::min(kDecChunk, count - f0);
-            mimi_decode_dev(b, b.latents.f() + static_cast<size_t>(first + f0) * L, static_cast<long long>(opt_.max_frames) * L, n,
+            mimi_decode_dev(b, b.latents.f() + static_cast<size_t>(first + f0) * L, static_cast<long long>(b.lat_frames) * L, n,
                             b.audio.f(), static_cast<long long>(kDecChunk) * fs, stream_);
             PTTS_HIP(hipMemcpyAsync(chunk_audio.data() + static_cast<size_t>(f0) * fs, b.audio.p, static_cast<size_t>(n) * fs * 4,
                                     hipMemcpyDeviceToHost, stream_));
@@ -446,7 +453,7 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
             fill_noise(rngs, one, step, hx);
             PTTS_HIP(hipMemcpyAsync(b.x0.p, hx, static_cast<size_t>(L) * 4, hipMemcpyHostToDevice, st));
         }
-        if (graph) PTTS_HIP(hipGraphLaunch(b.frame_exec[step & 1], st));                     // :753, :777-784
+        if (graph) PTTS_HIP(hipGraphLaunch(exec[step & 1], st));                     // :753, :777-784
         else frame_body(b, step & 1);
         for (unsigned spins = 1; __atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < step + 1; ++spins) {
             if ((spins & 0xffff) == 0 && hipStreamQuery(st) == hipSuccess && __atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < step + 1)
@@ -723,9 +730,9 @@ void Engine::op_mimi_decode(Batch* b, const float* latents, int n, float* audio)
     if (n <= 0 || n > kDecChunk) throw std::runtime_error("decoder chunk must hold 1..15 frames");
     if (n > opt_.max_frames) throw std::runtime_error("decoder chunk larger than max_frames");
     // stage the chunk at the front of each utterance's latent buffer
-    PTTS_HIP(hipMemcpy2DAsync(b->latents.p, static_cast<size_t>(opt_.max_frames) * L * 4, latents, static_cast<size_t>(n) * L * 4,
+    PTTS_HIP(hipMemcpy2DAsync(b->latents.p, static_cast<size_t>(b->lat_frames) * L * 4, latents, static_cast<size_t>(n) * L * 4,
                               static_cast<size_t>(n) * L * 4, b->B, hipMemcpyHostToDevice, stream_));
-    mimi_decode_dev(*b, b->latents.f(), static_cast<long long>(opt_.max_frames) * L, n, b->audio.f(), static_cast<long long>(kDecChunk) * fs, stream_);
+    mimi_decode_dev(*b, b->latents.f(), static_cast<long long>(b->lat_frames) * L, n, b->audio.f(), static_cast<long long>(kDecChunk) * fs, stream_);
     PTTS_HIP(hipMemcpy2DAsync(audio, static_cast<size_t>(n) * fs * 4, b->audio.p, static_cast<size_t>(kDecChunk) * fs * 4,
                               static_cast<size_t>(n) * fs * 4, b->B, hipMemcpyDeviceToHost, stream_));
     PTTS_HIP(hipStreamSynchronize(stream_));

@@ -48,6 +48,12 @@ constexpr int kMaxPieces = 4;  // float4 pieces per lane per row: C <= 1024
 template <typename WT> struct FlowTraits { static constexpr int pad = 4, kstep = 16, planes = 1; };
 template <> struct FlowTraits<__bf16> { static constexpr int pad = 8, kstep = 32, planes = 2; };
 
+// frame index read from device memory, optionally wrapped into a ring
+__device__ __forceinline__ long long step_idx(const int* p, int bias, int ring) {
+    const int v = *p + bias;
+    return ring > 0 ? v % ring : v;
+}
+
 __device__ __forceinline__ float silu_dev(float v) { return v / (1.0f + expf(-v)); }
 
 // Sum over the 64 lanes, the same value in every lane.  Four DPP steps (swap within pairs, swap pairs within
@@ -268,7 +274,7 @@ __device__ __forceinline__ void norm_modulate(const float4 (&h)[RPW][RowMap<C>::
 struct FlowBlockArgs {
     const float* x_in = nullptr; long long x_stride = 0;   // first block of a step: latent rows feeding the input projection
     const int* x_step = nullptr; long long x_step_stride = 0;          // optional device-side frame index (+ x_step_bias) added to x_in
-    int x_step_bias = 0;
+    int x_step_bias = 0, step_ring = 0;
     const float* h_prev = nullptr; float* h_next = nullptr;           // [B][C]
     const float* part_prev = nullptr; float* part_next = nullptr;     // [G][B][C]
     const float* mods = nullptr;      // this Euler step's adaLN vectors [B][mod_width]
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
                 float* redo = hbuf;                            // [waves][256]; hbuf is not in use yet
                 *(f32x4*)(redo + wave * 256 + lane * 4) = acco;
                 __syncthreads();
-                const float* xp = a.fin_x + (a.fin_x_step ? (long long)(*a.fin_x_step + a.x_step_bias) * a.fin_x_step_stride : 0);
+                const float* xp = a.fin_x + (a.fin_x_step ? step_idx(a.fin_x_step, a.x_step_bias, a.step_ring) * a.fin_x_step_stride : 0);
                 for (int i = tid; i < 16 * L; i += kFlowThreads) {
                     const int r = i / L, c = i % L;
                     float v = 0.f;
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
             }
         }
         if (!staged) {
-            const float* xin = a.x_in + (a.x_step ? (long long)(*a.x_step + a.x_step_bias) * a.x_step_stride : 0);
+            const float* xin = a.x_in + (a.x_step ? step_idx(a.x_step, a.x_step_bias, a.step_ring) * a.x_step_stride : 0);
             for (int i = tid; i < 16 * L; i += kFlowThreads) {
                 const int r = i / L, c = i % L;
                 const float v = r < nrows ? xin[(long long)(row0 + r) * a.x_stride + c] : 0.f;
@@ -624,7 +630,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_q8_kernel(FlowBlockAr
 
     float4 h[RPW][RM::NP];
     if (a.first) {
-        const float* xin = a.x_in + (a.x_step ? (long long)(*a.x_step + a.x_step_bias) * a.x_step_stride : 0);
+        const float* xin = a.x_in + (a.x_step ? step_idx(a.x_step, a.x_step_bias, a.step_ring) * a.x_step_stride : 0);
         for (int i = tid; i < 16 * L; i += kFlowThreads) {
             const int r = i / L, c = i % L;
             const float v = r < nrows ? xin[(long long)(row0 + r) * a.x_stride + c] : 0.f;
@@ -768,7 +774,7 @@ struct FlowFinalArgs {
     const float* h_prev = nullptr; const float* part_prev = nullptr;   // of the last block
     const float* mods = nullptr; const float* prev_b2 = nullptr;
     const float* x_in = nullptr; long long x_stride = 0;
-    const int* x_step = nullptr; long long x_step_stride = 0; int x_step_bias = 0;
+    const int* x_step = nullptr; long long x_step_stride = 0; int x_step_bias = 0, step_ring = 0;
     float* x_out = nullptr;                                            // [B][L]
     float* latents = nullptr; const int* lat_step = nullptr; int max_frames = 0;   // optional: also file x_out under frame *lat_step + x_step_bias
     const void* w_out = nullptr; const float* b_out = nullptr;
@@ -821,7 +827,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_final_kernel(FlowFinalArgs 
     one_row_finish<ONE>(acc);
     *(f32x4*)(red + wave * 256 + lane * 4) = acc;
     __syncthreads();
-    const float* xin = a.x_in + (a.x_step ? (long long)(*a.x_step + a.x_step_bias) * a.x_step_stride : 0);
+    const float* xin = a.x_in + (a.x_step ? step_idx(a.x_step, a.x_step_bias, a.step_ring) * a.x_step_stride : 0);
     for (int i = tid; i < 16 * L; i += kFlowThreads) {
         const int r = i / L, c = i % L;
         if (r >= nrows) continue;
@@ -832,7 +838,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_final_kernel(FlowFinalArgs 
         const long long row = row0 + r;
         const float xn = xin[row * a.x_stride + c] + (v + a.b_out[c]) * a.dt;
         a.x_out[row * L + c] = xn;
-        if (a.latents) a.latents[(row * a.max_frames + (*a.lat_step + a.x_step_bias)) * L + c] = xn;
+        if (a.latents) a.latents[(row * a.max_frames + step_idx(a.lat_step, a.x_step_bias, a.step_ring)) * L + c] = xn;
     }
 }
 
@@ -939,7 +945,7 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
             FlowBlockArgs fb;
             fb.x_in = x_in; fb.x_stride = x_stride;
             if (j == 0) { fb.x_step = a.x0_step; fb.x_step_stride = a.x0_step_stride; }
-            fb.x_step_bias = a.x0_step_bias;
+            fb.x_step_bias = a.x0_step_bias; fb.step_ring = a.step_ring;
             fb.h_prev = hb[cur ^ 1]; fb.h_next = hb[cur]; fb.part_prev = pb[cur ^ 1]; fb.part_next = pb[cur];
             fb.mods = mods_j; fb.prev_b2 = blk ? tabs.b_fc2[blk - 1] : nullptr;
             fb.first = blk == 0; fb.blk = blk;
@@ -967,7 +973,7 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
         ff.h_prev = hb[cur ^ 1]; ff.part_prev = pb[cur ^ 1]; ff.mods = mods_j; ff.prev_b2 = tabs.b_fc2[a.blocks - 1];
         ff.x_in = x_in; ff.x_stride = x_stride; ff.x_out = a.x_out;
         if (j == 0) { ff.x_step = a.x0_step; ff.x_step_stride = a.x0_step_stride; } ff.w_out = a.w_out; ff.b_out = a.b_out;
-        ff.x_step_bias = a.x0_step_bias;
+        ff.x_step_bias = a.x0_step_bias; ff.step_ring = a.step_ring;
         if (j + 1 == a.steps && a.latents) { ff.latents = a.latents; ff.lat_step = a.x0_step; ff.max_frames = a.max_frames; }
         ff.B = B; ff.blocks = a.blocks; ff.mod_width = a.mod_width; ff.eps = a.eps; ff.dt = 1.0f / (float)a.steps; ff.rpg = rpg;
         hipLaunchKernelGGL(kf, dim3(RG), dim3(kFlowThreads), smem_final, s, ff);

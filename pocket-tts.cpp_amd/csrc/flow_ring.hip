@@ -133,7 +133,7 @@ __device__ __forceinline__ bool ring_wait(unsigned* cnt, unsigned target, unsign
 }  // namespace
 
 struct FlowRingArgs {
-    const float* x0; long long x0_stride; const int* x0_step; long long x0_step_stride; int x0_step_bias;
+    const float* x0; long long x0_stride; const int* x0_step; long long x0_step_stride; int x0_step_bias, step_ring;
     float* x_out; float* latents; int max_frames;
     const float* mods;
     int B, blocks, steps, mod_width, replicas, ngroups;
@@ -211,6 +211,8 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
     const unsigned h_off_mine = (unsigned)((size_t)blk * BC * 4);
     const unsigned p_off_mine = (unsigned)(((size_t)a.blocks * BC + ((size_t)blk * G + g) * BC) * 4);
 
+    long long fidx = 0;   // frame index of this call, optionally wrapped into a ring
+    if (a.x0_step) { const int v = *a.x0_step + a.x0_step_bias; fidx = a.step_ring > 0 ? v % a.step_ring : v; }
     // One pass of the tail of an Euler step for the row group (block-0 workgroups): h of the last block's output ->
     // final adaLN -> output projection -> x += dt * v.  Leaves x in xk (LDS) and, bf16-split, in the X planes.
     auto step_tail = [&](const float* mods_prev, int row0, int nrows, float* xk, const float* xsrc, long long xsrc_stride, bool write_out) {
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
                 if (write_out) {
                     const long long row = row0 + r;
                     a.x_out[row * L + c] = v;
-                    if (a.latents) a.latents[(row * a.max_frames + (*a.x0_step + a.x0_step_bias)) * L + c] = v;
+                    if (a.latents) a.latents[(row * a.max_frames + fidx) * L + c] = v;
                 }
             }
             put1(X0, X1, r * LDX + c, v);
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
 
     const bool stamp_wg = a.stamps && rep == 0 && blk == (a.blocks > 3 ? 3 : 1) && g == 0 && tid == 0;
 #define RING_STAMP(i) do { if (stamp_wg && j == a.steps / 2 && q == rep) a.stamps[i] = __builtin_readcyclecounter(); } while (0)
-    const float* x0p = a.x0 + (a.x0_step ? (long long)(*a.x0_step + a.x0_step_bias) * a.x0_step_stride : 0);
+    const float* x0p = a.x0 + fidx * a.x0_step_stride;
 
     for (int j = 0; j < a.steps; ++j) {
         const float* mods_j = a.mods + (size_t)j * a.B * a.mod_width;
@@ -519,7 +521,7 @@ void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s) {
     int rpg = 4, replicas = 1;
     flow_ring_shape(a.B, a.blocks, a.ring_wg_budget, rpg, replicas);
     FlowRingArgs r{};
-    r.x0 = a.x0; r.x0_stride = a.x0_stride; r.x0_step = a.x0_step; r.x0_step_stride = a.x0_step_stride; r.x0_step_bias = a.x0_step_bias;
+    r.x0 = a.x0; r.x0_stride = a.x0_stride; r.x0_step = a.x0_step; r.x0_step_stride = a.x0_step_stride; r.x0_step_bias = a.x0_step_bias; r.step_ring = a.step_ring;
     r.x_out = a.x_out; r.latents = a.latents; r.max_frames = a.max_frames;
     r.mods = a.mods; r.B = a.B; r.blocks = a.blocks; r.steps = a.steps; r.mod_width = a.mod_width;
     r.replicas = replicas; r.ngroups = (a.B + rpg - 1) / rpg;

@@ -86,6 +86,13 @@ void launch_embed_rows(const long long* ids, int T, const float* table, int voca
 // mode 1: y = x * std[c] + mean[c]          (latent de-normalisation in front of the decoder)
 void launch_prep_latent(const float* x, float* y, int rows, int L, int mode, const float* p0, const float* p1, hipStream_t s);
 
+// Decoder input of a chunk taken from per-slot latent rings: z[b][i][:] = lat[(slot0 + b)][(start + i) % ring][:] * std + mean
+// for b < nb, i < n  (lat: [slots][ring][L]).
+void launch_gather_latents(const float* lat, int ring, int slot0, int nb, int start, int n, int L, const float* stdv, const float* mean, float* z,
+                           hipStream_t s);
+// pos[i] = 0 for every i < 64 whose bit is set in mask
+void launch_reset_pos_mask(int* pos, unsigned long long mask, hipStream_t s);
+
 // eos[m] = dot(X[m], w) + b
 void launch_rowdot(const float* X, int ldx, int M, int D, const float* w, const float* b, float* out, hipStream_t s);
 
@@ -134,6 +141,7 @@ struct FlowHeadArgs {
     long long x0_stride = 0;
     const int* x0_step = nullptr; long long x0_step_stride = 0;
     int x0_step_bias = 0;         // added to *x0_step wherever it is used
+    int step_ring = 0;            // > 0: the frame index (*x0_step + bias) is taken modulo this (start points and latents kept in rings)
     float* latents = nullptr; int max_frames = 0;   // optional (needs x0_step): x_out is also filed as latents[b][*x0_step + bias][:]
     hipEvent_t probe_a = nullptr, probe_b = nullptr;   // optional: recorded around the whole chain of steps * (blocks + 1) launches
     float* x_out = nullptr;       // [B][L]; also carries x between Euler steps (must not alias x0)
@@ -232,6 +240,8 @@ void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
 // in mapped host memory, then h_flag = *step + 1 and *step += 1 (so later kernels of the frame see the index plus one).
 struct FramePublish {
     const float* eos = nullptr; int* step = nullptr; float* h_eos_all = nullptr; int* h_flag = nullptr;
+    int ring = 0;     // > 0: h_eos_all is a ring of this many steps (row = *step % ring)
+    int stride = 0;   // > 0: floats per step row of h_eos_all (default: B)
 };
 // zero / zero_words (optional): words the launch also sets to zero (the control words of a later kernel of the same frame)
 void launch_flow_mod_input(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C, hipStream_t s,

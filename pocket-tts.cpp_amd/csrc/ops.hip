@@ -218,6 +218,29 @@ void launch_advance_pos(int* pos, int n, int delta, hipStream_t s) {
     hipLaunchKernelGGL(advance_pos_kernel, dim3((n + 63) / 64), dim3(64), 0, s, pos, n, delta);
 }
 
+__global__ void reset_pos_mask_kernel(int* pos, unsigned long long mask) {
+    const int i = threadIdx.x;
+    if ((mask >> i) & 1ull) pos[i] = 0;
+}
+void launch_reset_pos_mask(int* pos, unsigned long long mask, hipStream_t s) {
+    if (mask) hipLaunchKernelGGL(reset_pos_mask_kernel, dim3(1), dim3(64), 0, s, pos, mask);
+}
+
+__global__ void gather_latents_kernel(const float* lat, int ring, int slot0, int nb, int start, int n, int L, const float* stdv, const float* mean,
+                                      float* z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb * n * L) return;
+    const int c = i % L, f = (i / L) % n, b = i / (L * n);
+    const float v = lat[((long long)(slot0 + b) * ring + (start + f) % ring) * L + c];
+    z[i] = v * stdv[c] + mean[c];
+}
+void launch_gather_latents(const float* lat, int ring, int slot0, int nb, int start, int n, int L, const float* stdv, const float* mean, float* z,
+                           hipStream_t s) {
+    const int total = nb * n * L;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(gather_latents_kernel, dim3((total + 255) / 256), dim3(256), 0, s, lat, ring, slot0, nb, start, n, L, stdv, mean, z);
+}
+
 __global__ void advance_pos_vec_kernel(int* pos, const int* delta, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) pos[i] += delta[i];
@@ -438,7 +461,8 @@ __global__ void flow_mod_input_kernel(const float* te, const float* cemb, int sp
     }
     if (pub.step && blockIdx.x == 0) {   // frame bookkeeping: see FramePublish
         const int st = *pub.step;
-        for (int b = threadIdx.x; b < B; b += blockDim.x) pub.h_eos_all[(long long)st * B + b] = pub.eos[b];
+        const long long row = (long long)(pub.ring > 0 ? st % pub.ring : st) * (pub.stride > 0 ? pub.stride : B);
+        for (int b = threadIdx.x; b < B; b += blockDim.x) pub.h_eos_all[row + b] = pub.eos[b];
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) {
