@@ -44,7 +44,8 @@ POCKET_TTS_API VoiceHandle pocket_tts_voice_from_embeddings(const float* embeddi
 POCKET_TTS_API int pocket_tts_voice_frames(VoiceHandle voice);
 POCKET_TTS_API const float* pocket_tts_voice_data(VoiceHandle voice);
 
-/* n utterances generated in lock step on one GPU (offline schedule of src/pocket_tts.cpp:548-657 for each).
+/* n utterances (any n) through the engine's slot table: up to 64 are in flight on the GPU, each with the offline schedule of
+ * src/pocket_tts.cpp:548-657, and a slot whose utterance has stopped is refilled from the rest.
  * results[i] is filled like pocket_tts_generate does; release each with pocket_tts_free_audio. */
 POCKET_TTS_API int pocket_tts_generate_batch(PocketTTSHandle handle, int n, const char* const* texts,
                                              const VoiceHandle* voices, AudioResult* results);
@@ -57,6 +58,12 @@ POCKET_TTS_API int pocket_tts_generate_ids(PocketTTSHandle handle, int n, const 
                                            const float* const* voices, const int* voice_frames,
                                            const float* const* noise, AudioResult* results, float* const* latents_out,
                                            float* const* eos_out, int* frames_out, int* eos_count_out);
+
+/* The same through the slot table (queue with slot refill, any n): utterances finish and are replaced independently. */
+POCKET_TTS_API int pocket_tts_generate_ids_queued(PocketTTSHandle handle, int n, const long long* const* ids, const int* n_ids,
+                                                  const float* const* voices, const int* voice_frames,
+                                                  const float* const* noise, AudioResult* results, float* const* latents_out,
+                                                  float* const* eos_out, int* frames_out, int* eos_count_out);
 
 /* pocket_tts_generate_ids in three parts, for callers that time or overlap the device-resident middle:
  *   stage : host -> HBM copy of ids, conditioning rows and start points; returns a batch owned by the engine
@@ -153,9 +160,12 @@ POCKET_TTS_API int ptts_bf16_linear(PocketTTSHandle handle, const float* A, int 
                                     const float* colscale, const float* R, int act, int flags, float* out);
 
 POCKET_TTS_API int ptts_phase_timing(PocketTTSHandle handle, int enable);
-/* Coalescing of concurrent single-utterance calls (pocket_tts_generate, pocket_tts_generate_ids with n = 1):
- * stats[0] = batches run, stats[1] = utterances served, stats[2] = largest batch. */
+/* The slot table that serves pocket_tts_generate, pocket_tts_generate_streaming, pocket_tts_generate_batch and the _queued calls:
+ * stats[0] = activations of the table (idle -> busy), stats[1] = utterances served, stats[2] = most slots occupied at once. */
 POCKET_TTS_API int ptts_scheduler_stats(PocketTTSHandle handle, long* stats);
+/* ... and stats[3] = frame steps launched, [4] = sum of the launch width over them, [5] = frames delivered to callers,
+ * [6] = decoder chunk calls, [7] = prefill passes (8 entries). */
+POCKET_TTS_API int ptts_scheduler_stats_ex(PocketTTSHandle handle, long* stats);
 POCKET_TTS_API int ptts_phase_times(PocketTTSHandle handle, double* times_ms, long* calls);
 /* bytes[0..3] = GEMM weight bytes (compute precision) of the LM, the flow head, the decoder, the encoder */
 POCKET_TTS_API int ptts_weight_bytes(PocketTTSHandle handle, unsigned long long* bytes);

@@ -240,16 +240,15 @@ POCKET_TTS_API int pocket_tts_generate_batch(PocketTTSHandle handle, int n, cons
             utts[i].voice_frames = static_cast<int>(v->shape[1]);
         }
         std::vector<ptts::UtteranceResult> res;
-        tts->engine().generate(utts, res, false);
+        tts->engine().generate_queue(utts, res, false);   // slot table: any n, finished slots are refilled from the rest
         for (int i = 0; i < n; ++i) fill_result(&results[i], res[i].audio, tts->engine().spec().sample_rate);
         return 0;
     });
 }
 
-POCKET_TTS_API int pocket_tts_generate_ids(PocketTTSHandle handle, int n, const long long* const* ids, const int* n_ids,
-                                           const float* const* voices, const int* voice_frames, const float* const* noise,
-                                           AudioResult* results, float* const* latents_out, float* const* eos_out, int* frames_out,
-                                           int* eos_count_out) {
+static int generate_ids_impl(PocketTTSHandle handle, int n, const long long* const* ids, const int* n_ids, const float* const* voices,
+                             const int* voice_frames, const float* const* noise, AudioResult* results, float* const* latents_out,
+                             float* const* eos_out, int* frames_out, int* eos_count_out, bool queued) {
     if (!handle || n < 0 || (n > 0 && (!ids || !n_ids || !voices || !voice_frames))) { set_error("Invalid parameters"); return -1; }
     return guarded("Failed to generate: ", [&] {
         auto* tts = tts_of(handle);
@@ -262,7 +261,9 @@ POCKET_TTS_API int pocket_tts_generate_ids(PocketTTSHandle handle, int n, const 
             utts[i].noise = noise ? noise[i] : nullptr;
         }
         std::vector<ptts::UtteranceResult> res;
-        if (n == 1) {   // single utterances go through the coalescing queue like pocket_tts_generate
+        if (queued) {
+            tts->engine().generate_queue(utts, res, want);
+        } else if (n == 1) {   // single utterances share the slot table with concurrent callers, like pocket_tts_generate
             res.resize(1);
             tts->engine().generate_one(utts[0], res[0], want);
         } else {
@@ -278,6 +279,20 @@ POCKET_TTS_API int pocket_tts_generate_ids(PocketTTSHandle handle, int n, const 
         }
         return 0;
     });
+}
+
+POCKET_TTS_API int pocket_tts_generate_ids(PocketTTSHandle handle, int n, const long long* const* ids, const int* n_ids,
+                                           const float* const* voices, const int* voice_frames, const float* const* noise,
+                                           AudioResult* results, float* const* latents_out, float* const* eos_out, int* frames_out,
+                                           int* eos_count_out) {
+    return generate_ids_impl(handle, n, ids, n_ids, voices, voice_frames, noise, results, latents_out, eos_out, frames_out, eos_count_out, false);
+}
+
+POCKET_TTS_API int pocket_tts_generate_ids_queued(PocketTTSHandle handle, int n, const long long* const* ids, const int* n_ids,
+                                                  const float* const* voices, const int* voice_frames, const float* const* noise,
+                                                  AudioResult* results, float* const* latents_out, float* const* eos_out, int* frames_out,
+                                                  int* eos_count_out) {
+    return generate_ids_impl(handle, n, ids, n_ids, voices, voice_frames, noise, results, latents_out, eos_out, frames_out, eos_count_out, true);
 }
 
 POCKET_TTS_API void* pocket_tts_stage_ids(PocketTTSHandle handle, int n, const long long* const* ids, const int* n_ids,
@@ -526,6 +541,16 @@ POCKET_TTS_API int ptts_scheduler_stats(PocketTTSHandle handle, long* stats) {
     return guarded("scheduler_stats: ", [&] {
         auto st = tts_of(handle)->engine().scheduler_stats();
         stats[0] = st.batches; stats[1] = st.utterances; stats[2] = st.largest;
+        return 0;
+    });
+}
+
+POCKET_TTS_API int ptts_scheduler_stats_ex(PocketTTSHandle handle, long* stats) {
+    if (!handle || !stats) { set_error("Invalid parameters"); return -1; }
+    return guarded("scheduler_stats: ", [&] {
+        auto st = tts_of(handle)->engine().scheduler_stats();
+        stats[0] = st.batches; stats[1] = st.utterances; stats[2] = st.largest; stats[3] = st.frame_steps; stats[4] = st.slot_steps;
+        stats[5] = st.frames; stats[6] = st.decode_calls; stats[7] = st.admissions;
         return 0;
     });
 }

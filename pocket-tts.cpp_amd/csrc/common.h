@@ -21,6 +21,13 @@ namespace ptts {
                                      __FILE__ + ":" + std::to_string(__LINE__) + " (" #expr ")");   \
     } while (0)
 
+// Set POCKET_TTS_TRACE=1 to follow engine set-up, tear-down and scheduler activations on stderr.
+void trace_line(const char* what);
+bool trace_on();
+void trace_fmt(const char* fmt, ...) __attribute__((format(printf, 1, 2)));   // with a microsecond time stamp
+#define PTTS_TRACE(what) ::ptts::trace_line(what)
+#define PTTS_TRACEF(...) do { if (::ptts::trace_on()) ::ptts::trace_fmt(__VA_ARGS__); } while (0)
+
 // Every dimension of the five networks; read from the pack header, never compiled in.
 struct Spec {
     int latent = 0, d_model = 0, lm_layers = 0, lm_heads = 0, lm_ffn = 0, lm_max_period = 0, vocab = 0;

@@ -487,6 +487,7 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
         throw std::runtime_error("no HIP device available: the MI355X engine has no CPU fallback");
     if (opt_.device < 0 || opt_.device >= ndev) throw std::runtime_error("engine: device ordinal out of range");
     PTTS_HIP(hipSetDevice(opt_.device));
+    PTTS_TRACE("ctor: device set");
     // Spatial split of the compute units: the decoder stream is confined to k of every 8 blocks of 8 CUs
     // (POCKET_TTS_DECODER_CU_EIGHTHS, default 4, 0 = no mask), so its wide kernels always leave CUs free for the
     // frame loop's small dependent launches.  Measured at B = 64 on MI355X: no mask 3350 RTFx, k = 4 3620, k = 3 3540,
@@ -537,8 +538,10 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
         lane_streams_.push_back(ls);
         lane_events_.push_back(le);
     }
+    PTTS_TRACE("ctor: streams made");
     Pack pack(opt_.pack_path);
     model_ = std::make_unique<Model>(pack, opt_.precision);
+    PTTS_TRACE("ctor: model uploaded");
     const Spec& s = model_->spec();
     const int lm_len = 64 + opt_.max_text_tokens + opt_.max_frames + 8 + 64;
     const int mimi_len = std::max((opt_.max_frames + kDecChunk) * s.upsample + 64, 2048);
@@ -609,18 +612,26 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
                             resblock_supported(c, s.res_kernel, hd_.dec_c1[i].wtype);
         }
     }
+    PTTS_TRACE("ctor: before flow prepare");
     flow_head_prepare(s.flow_dim, model_->flow_wtype);
     init_static_scratch();
+    PTTS_TRACE("ctor: static scratch resolved");
     flow_te_.alloc(te.size() * 4);
     PTTS_HIP(hipMemcpy(flow_te_.p, te.data(), te.size() * 4, hipMemcpyHostToDevice));
     PTTS_HIP(hipEventCreate(&ev_[0]));
     PTTS_HIP(hipEventCreate(&ev_[1]));
+    PTTS_TRACE("ctor: done");
 }
 
 Engine::~Engine() {
+    PTTS_TRACE("dtor: begin");
+    stop_worker();
+    PTTS_TRACE("dtor: worker joined");
     (void)hipSetDevice(opt_.device);
     (void)hipStreamSynchronize(stream_);
     batch_pool_.clear();
+    drop_table();
+    PTTS_TRACE("dtor: table dropped");
     for (auto& pe : pending_events_) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     if (ev_[0]) (void)hipEventDestroy(ev_[0]);
     if (ev_[1]) (void)hipEventDestroy(ev_[1]);
@@ -633,6 +644,7 @@ Engine::~Engine() {
     if (dec_done_) (void)hipEventDestroy(dec_done_);
     if (dec_stream_) { (void)hipStreamSynchronize(dec_stream_); (void)hipStreamDestroy(dec_stream_); }
     if (stream_) (void)hipStreamDestroy(stream_);
+    PTTS_TRACE("dtor: streams destroyed");
 }
 
 void Engine::enable_phase_timing(bool on) { timing_ = on; times_ = PhaseTimes(); }
@@ -986,7 +998,10 @@ void Engine::check_flow_ring(const unsigned* ctl, int rows) {
     if (!ctl || model_->flow_wtype != W_BF16 || spec().flow_dim != 512) return;
     unsigned err = 0;
     PTTS_HIP(hipMemcpy(&err, ctl + flow_ring_err_word(rows, spec().flow_blocks), 4, hipMemcpyDeviceToHost));
-    if (err) throw std::runtime_error("flow head: a hand-off between workgroups timed out (the persistent launch was not fully resident)");
+    if (err) {
+        PTTS_HIP(hipMemset(const_cast<unsigned*>(ctl), 0, 4));
+        throw std::runtime_error("flow head: a hand-off between workgroups timed out (the persistent launch was not fully resident)");
+    }
 }
 
 // frame (optional): the batch whose frame bookkeeping (EOS publication, frame counter, latent filing) rides in the launches
@@ -1012,8 +1027,9 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
     probe.C = C; probe.L = s.latent; probe.blocks = s.flow_blocks; probe.steps = N; probe.B = B; probe.wtype = model_->flow_wtype;
     probe.block_wtype = model_->flow_block_wtype; probe.ring_ctl = fs.ctl; probe.ring_wg_budget = 224 / std::max(lanes_, 1);
     const bool ring = fs.ctl && flow_ring_supported(probe);
-    launch_flow_mod_input(flow_te_.f(), fs.cemb, cs, hd_.flow_cond_b, fs.ymod, N, B, C, st, frame ? &pub : nullptr, ring ? fs.ctl : nullptr,
-                          ring ? static_cast<int>(flow_ring_ctl_bytes(B, s.flow_blocks) / 4) : 0);
+    const int cw = static_cast<int>(flow_ring_counter_word());
+    launch_flow_mod_input(flow_te_.f(), fs.cemb, cs, hd_.flow_cond_b, fs.ymod, N, B, C, st, frame ? &pub : nullptr, ring ? fs.ctl + cw : nullptr,
+                          ring ? static_cast<int>(flow_ring_ctl_bytes(B, s.flow_blocks) / 4) - cw : 0);
     if (model_->ada_packed) {
         SkinnyArgs m;
         m.A = fs.ymod; m.lda = C; m.Wp = model_->ada_packed; m.wtype = wt; m.M = N * B; m.N = model_->mod_width; m.K = C;
@@ -1046,7 +1062,7 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
 // latent rows (batched mapping: utterance b at lat_dev + b*lat_bs, n rows of `latent` floats)
 // -> audio[b][n*frame]   (src/pocket_tts.cpp:454-546 for one chunk of n <= 15 frames)
 void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs, hipStream_t st,
-                             int slot0, int nb, int ring_start) {
+                             int slot0, int nb, int ring_start, unsigned long long due_mask) {
     const Spec& s = spec();
     if (n <= 0 || n > kDecChunk) throw std::runtime_error("decoder chunk must hold 1..15 frames");
     if (nb < 0) nb = b.B - slot0;
@@ -1054,7 +1070,7 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
     const int B = nb, L = s.latent, M = s.mimi_dim, U = s.upsample;
     const int T0 = n * U, T0max = kDecChunk * U;
     for (int i = slot0; i < slot0 + nb; ++i)
-        if (b.dec_pos_host[i] + T0 > model_->mimi_tab_len) throw std::runtime_error("decoder position exceeds the rotary table");
+        if ((due_mask == ~0ull || ((due_mask >> i) & 1ull)) && b.dec_pos_host[i] + T0 > model_->mimi_tab_len) throw std::runtime_error("decoder position exceeds the rotary table");
     phase_begin(2, st);
     // the chunk's latent rows, de-normalised
     if (ring_start >= 0) {
@@ -1154,10 +1170,10 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
     }
     launch_conv_to_mono(prev, prev_bf16, prev_bs, T, s.last_kernel * c, c, hd_.dec_final_w, hd_.dec_final_b, audio_dev, audio_bs, B, st);
     // carry the streaming histories and positions to the next chunk
-    launch_shift_history(qbuf0, qbs, n, 1, M, B, st);
-    launch_shift_history(ybuf0, ybs, T0, H0, M, B, st);
+    launch_shift_history(qbuf0, qbs, n, 1, M, B, st, due_mask, slot0);
+    launch_shift_history(ybuf0, ybs, T0, H0, M, B, st, due_mask, slot0);
     c = 8 * s.n_filters;
-    launch_shift_history(e0buf0, static_cast<long long>(1 + T0max) * c, T0, 1, c, B, st);
+    launch_shift_history(e0buf0, static_cast<long long>(1 + T0max) * c, T0, 1, c, B, st, due_mask, slot0);
     T = T0; Tmax = T0max;
     for (int i = 0; i < 3; ++i) {
         const int co = c / 2, rk = s.res_kernel, hn = i < 2 ? 1 : s.last_kernel - 1;
@@ -1165,12 +1181,13 @@ void Engine::mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, i
         // bf16 rows of a fused stage: the same bytes seen as co/2 floats per row
         const int div = dec_fused_[i] ? 2 : 1;
         const long long ubs = static_cast<long long>(rk - 1 + Tmax) * co / div, ebs = static_cast<long long>(hn + Tmax) * co / div;
-        launch_shift_history(b.uebuf[i].f() + slot0 * ubs, ubs, T, rk - 1, co / div, B, st);
-        launch_shift_history(b.ebuf[i].f() + slot0 * ebs, ebs, T, hn, co / div, B, st);
+        launch_shift_history(b.uebuf[i].f() + slot0 * ubs, ubs, T, rk - 1, co / div, B, st, due_mask, slot0);
+        launch_shift_history(b.ebuf[i].f() + slot0 * ebs, ebs, T, hn, co / div, B, st, due_mask, slot0);
         c = co;
     }
-    launch_advance_pos(b.dec_pos.as<int>() + slot0, B, T0, st);
-    for (int i = slot0; i < slot0 + nb; ++i) b.dec_pos_host[i] += T0;
+    launch_advance_pos(b.dec_pos.as<int>() + slot0, B, T0, st, due_mask, slot0);
+    for (int i = slot0; i < slot0 + nb; ++i)
+        if (due_mask == ~0ull || ((due_mask >> i) & 1ull)) b.dec_pos_host[i] += T0;
     phase_end(2, st);
     check_launches("the decoder chunk");
 }

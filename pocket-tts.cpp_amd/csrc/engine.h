@@ -16,6 +16,7 @@
 #include <mutex>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -150,11 +151,23 @@ public:
     // ---- whole-path entry points (lock-step batch of independent utterances) ----
     // Offline: /root/reference/src/pocket_tts.cpp:548-657 for every utterance of the batch.
     void generate(const std::vector<Utterance>& utts, std::vector<UtteranceResult>& out, bool want_latents);
-    // One utterance from any thread.  Calls that arrive while a batch is running are queued and leave together
-    // as the next lock-step batch (up to kMaxCoalesce), so concurrent callers of the single-utterance API share
-    // the GPU instead of taking turns (scheduler.cpp).
+    // One utterance from any thread, through the slot table (scheduler.cpp): a worker thread steps up to kSlots utterances
+    // per frame; an utterance takes a free slot when it arrives (offline calls at the next 15-frame boundary of the table's
+    // clock, so that their decoder chunks stay aligned) and gives it back when its stop rule fires, so concurrent callers of
+    // the single-utterance API share the GPU and nobody waits for the longest utterance of a batch.
     void generate_one(const Utterance& utt, UtteranceResult& out, bool want_latents);
-    struct SchedulerStats { long batches = 0, utterances = 0, largest = 0; };
+    // Any number of utterances through the same table (queue with slot refill); returns when all are done.
+    void generate_queue(const std::vector<Utterance>& utts, std::vector<UtteranceResult>& out, bool want_latents);
+    struct SchedulerStats {
+        long batches = 0;       // activations of the slot table (idle -> busy)
+        long utterances = 0;    // utterances served
+        long largest = 0;       // most slots occupied at once
+        long frame_steps = 0;   // frame steps launched
+        long slot_steps = 0;    // sum of the launch width over those steps
+        long frames = 0;        // frames delivered to callers
+        long decode_calls = 0;  // decoder chunk calls
+        long admissions = 0;    // prefill passes
+    };
     SchedulerStats scheduler_stats();
     // The same in three parts, so a benchmark can time the device-resident middle on its own:
     //   stage (host -> HBM), run_staged (prefill + frame loop + decode, audio left in HBM), fetch_staged (HBM -> host).
@@ -167,9 +180,14 @@ public:
     // Streaming, single utterance: /root/reference/src/pocket_tts.cpp:686-979.  Returns total samples.
     // cancel_flag (may be null) is polled once per frame when poll_cancel is set, and always suppresses the
     // tail flush when raised.
+    // Rides in the slot table beside other callers' utterances; the callback runs on the calling thread.
+    // POCKET_TTS_INLINE_STREAMING=1: the whole loop on the calling thread with a batch of its own (generate_streaming_inline).
     int generate_streaming(const Utterance& utt, int chunk_frames, const ChunkCallback& cb,
                            const std::atomic<bool>* cancel_flag, bool poll_cancel, const std::function<void(int)>& progress,
                            UtteranceResult* capture);
+    int generate_streaming_inline(const Utterance& utt, int chunk_frames, const ChunkCallback& cb,
+                                  const std::atomic<bool>* cancel_flag, bool poll_cancel, const std::function<void(int)>& progress,
+                                  UtteranceResult* capture);
     // Voice encoder: audio f32[S] at the model rate -> [frames][d_model]  (src/pocket_tts.cpp:261-291)
     std::vector<float> encode_voice(const float* audio, int S);
     void encode_voice_batch(const std::vector<const float*>& clips, const std::vector<int>& lens,
@@ -224,9 +242,10 @@ private:
     // After the stream has drained: throws if a hand-off wait of the persistent flow head gave up during the calls since the last check.
     void check_flow_ring(const unsigned* ctl, int rows);
     // slot0 / nb: the contiguous range of slots the chunk is decoded for (nb < 0: all).  ring_start >= 0: the latent rows come from
-    // the batch's latent rings starting at that ring index instead of lat_dev.
+    // the batch's latent rings starting at that ring index instead of lat_dev.  due_mask: slots (bit = slot index) whose streaming state
+    // the chunk advances; the others are computed along and left as they were.
     void mimi_decode_dev(Batch& b, const float* lat_dev, long long lat_bs, int n, float* audio_dev, long long audio_bs, hipStream_t st,
-                         int slot0 = 0, int nb = -1, int ring_start = -1);
+                         int slot0 = 0, int nb = -1, int ring_start = -1, unsigned long long due_mask = ~0ull);
     void prefill_utterance(Batch& b, int slot, const Utterance& u);
     void fill_noise(std::vector<std::mt19937>& rngs, const std::vector<Utterance>& utts, int step, float* host_x0);
     Batch* acquire_batch(int B, int lane = 0);
@@ -263,14 +282,27 @@ private:
     bool dec_fused_[3] = {false, false, false};   // decoder stages whose residual unit runs as one fused kernel
     bool use_graph_ = true;                     // replay each frame as one hipGraph (POCKET_TTS_NO_GRAPH=1: eager launches)
     Job job_;
-    // coalescing queue of generate_one
-    struct Pending { const Utterance* utt; UtteranceResult* out; bool want_latents; std::exception_ptr err; bool done = false; };
-    static constexpr size_t kMaxCoalesce = 64;
+    // slot-table scheduler (scheduler.cpp)
+public:
+    struct Request;
+    static constexpr int kSlots = 64;
+private:
+    struct Table;
+    void validate_request(const Utterance& utt) const;
+    void submit(Request& r);
+    void submit_all(Request* const* reqs, size_t n);
+    void worker_main();
+    void stop_worker();
+    void drop_table();
+    void run_table();
+    Table* table_ = nullptr;   // owned; created by the first activation, freed by drop_table()
+    std::thread worker_;
+    bool worker_started_ = false, worker_stop_ = false;
     std::mutex q_mu_;
     std::condition_variable q_cv_;
-    std::deque<Pending*> queue_;
-    bool leader_active_ = false;
+    std::deque<Request*> queue_;
     SchedulerStats sched_stats_;
+    DevBuf bos_row_;   // the BOS embedding as a latent row (what the reference's NaN marker stands for)
     std::mutex ev_mu_;
     bool timing_ = false;
     hipEvent_t ev_[2] = {nullptr, nullptr};

@@ -393,9 +393,9 @@ void Engine::generate(const std::vector<Utterance>& utts, std::vector<UtteranceR
         for (size_t i = 0; i < out.size(); ++i) out[i].eos = std::move(eos[i]);
 }
 
-int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const ChunkCallback& cb,
-                               const std::atomic<bool>* cancel_flag, bool poll_cancel, const std::function<void(int)>& progress,
-                               UtteranceResult* capture) {
+int Engine::generate_streaming_inline(const Utterance& utt, int chunk_frames, const ChunkCallback& cb,
+                                      const std::atomic<bool>* cancel_flag, bool poll_cancel, const std::function<void(int)>& progress,
+                                      UtteranceResult* capture) {
     if (!cb) throw std::invalid_argument("Callback must be provided");  // :693-695
     if (chunk_frames <= 0) chunk_frames = 1;  // size() >= 0 holds after every frame (:790)
     std::lock_guard<std::recursive_mutex> call(call_mu_);

@@ -142,7 +142,7 @@ struct FlowRingArgs {
     const float* b1[kFlowRingMaxBlocks]; const float* b2[kFlowRingMaxBlocks];
     const float* ln_g[kFlowRingMaxBlocks]; const float* ln_b[kFlowRingMaxBlocks];
     float* ws; unsigned ws_bytes;        // hstage [blocks][B][C] then part [blocks][G][B][C], f32
-    unsigned* ctl;                       // counters [blocks][ngroups] one per 128-byte line, then the error word
+    unsigned* ctl;                       // the error word, then counters [blocks][ngroups], one per 128-byte line
     float eps, dt;
     long long* stamps;                   // optional [16]: cycle counter along one mid-chain visit (tuning aid)
 };
@@ -171,7 +171,8 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
     static_assert(RPG == 4, "flow ring: one accumulator row per 16-lane group");
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)a.ws_bytes, 0x00020000);
     const size_t BC = (size_t)a.B * C;
-    unsigned* err = a.ctl + (size_t)a.blocks * a.ngroups * kCtlStride;
+    unsigned* err = a.ctl;                               // word 0; the counters follow from word kCtlStride on
+    unsigned* const cnt0 = a.ctl + kCtlStride;
     const bool first_blk = blk == 0;
 
     // ---- this workgroup's matrices, once: fc1 tile `wave` of slice g over all of K; fc2 tiles 8 * wave .. 8 * wave + 7
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
             // ---- wait for the producers of this row group
             if (!first_blk || j > 0) {
                 if (tid == 0) {
-                    unsigned* cnt = a.ctl + ((size_t)pblk * a.ngroups + q) * kCtlStride;
+                    unsigned* cnt = cnt0 + ((size_t)pblk * a.ngroups + q) * kCtlStride;
                     const unsigned target = (unsigned)G * (unsigned)(first_blk ? j : j + 1);
                     *sflag = ring_wait(cnt, target, err) ? 1 : 0;
                     RING_STAMP(1);
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             RING_STAMP(7);
             __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(a.ctl + ((size_t)blk * a.ngroups + q) * kCtlStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_fetch_add(cnt0 + ((size_t)blk * a.ngroups + q) * kCtlStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             RING_STAMP(8);
         }
     }
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
             const int row0 = q * RPG;
             const int nrows = (a.B - row0) < RPG ? (a.B - row0) : RPG;
             if (tid == 0) {
-                unsigned* cnt = a.ctl + ((size_t)pblk * a.ngroups + q) * kCtlStride;
+                unsigned* cnt = cnt0 + ((size_t)pblk * a.ngroups + q) * kCtlStride;
                 *sflag = ring_wait(cnt, (unsigned)G * (unsigned)a.steps, err) ? 1 : 0;
             }
             __syncthreads();
@@ -492,8 +493,10 @@ size_t flow_ring_ctl_bytes(int B, int blocks) {
     return ((size_t)blocks * ngroups * kCtlStride + kCtlStride) * sizeof(unsigned);
 }
 
-// Word index of the error word inside the control block (non-zero after a launch: a hand-off wait gave up).
-size_t flow_ring_err_word(int B, int blocks) { return (size_t)blocks * ((B + 3) / 4) * kCtlStride; }
+// Control block: word 0 = error word (set when a hand-off wait gave up; cleared by the host only), then from word
+// flow_ring_counter_word() on the (block, row group) counters, which an earlier kernel of the frame zeroes.
+size_t flow_ring_err_word(int, int) { return 0; }
+size_t flow_ring_counter_word() { return kCtlStride; }
 
 static size_t ring_smem(int rpg, int ngroups, int replicas) {
     const int local = (ngroups + replicas - 1) / replicas;

@@ -70,7 +70,8 @@ void launch_attention(const AttentionArgs& a, hipStream_t s);
 void launch_attention_tiled(const AttentionArgs& a, hipStream_t s);   // rpb rows per slot, M % rpb == 0
 
 // pos[i] += delta for i < n
-void launch_advance_pos(int* pos, int n, int delta, hipStream_t s);
+// mask (with slot0 = index of pos[0] in it): only slots whose bit is set advance; ~0: all
+void launch_advance_pos(int* pos, int n, int delta, hipStream_t s, unsigned long long mask = ~0ull, int slot0 = 0);
 // pos[i] += delta[i] for i < n
 void launch_advance_pos_vec(int* pos, const int* delta, int n, hipStream_t s);
 
@@ -90,8 +91,41 @@ void launch_prep_latent(const float* x, float* y, int rows, int L, int mode, con
 // for b < nb, i < n  (lat: [slots][ring][L]).
 void launch_gather_latents(const float* lat, int ring, int slot0, int nb, int start, int n, int L, const float* stdv, const float* mean, float* z,
                            hipStream_t s);
+// *p = v
+void launch_poke_int(int* p, int v, hipStream_t s);
 // pos[i] = 0 for every i < 64 whose bit is set in mask
 void launch_reset_pos_mask(int* pos, unsigned long long mask, hipStream_t s);
+
+// Admission of up to 64 prefilled utterances into slots of a slot table, one launch: the K/V rows [layer][len] of staging
+// slot i go to table slot slot[i] (caches laid out [layer][slot][cap][row_bytes]), the slot's position becomes len[i], its
+// current latent row the BOS row, and its start-point ring rows (g0 + f) % ring, f < frames, are taken from
+// noise_stage[i][frames][L] (has_noise[i]) or zeroed.
+struct AdmitArgs {
+    int k = 0, layers = 0, row_bytes = 0, cap = 0, dst_slots = 0, src_slots = 0;
+    char *k_dst = nullptr, *v_dst = nullptr;
+    const char *k_src = nullptr, *v_src = nullptr;
+    int* lm_pos = nullptr;
+    float* xcur = nullptr;
+    const float* bos = nullptr;
+    int L = 0, ring = 0, frames = 0, g0 = 0;
+    float* noise_ring = nullptr;
+    const float* noise_stage = nullptr;
+    unsigned char slot[64] = {}, has_noise[64] = {};
+    int len[64] = {};
+};
+void launch_admit(const AdmitArgs& a, hipStream_t s);
+
+// Streaming-decoder state of the given slots back to "no history": for each of nbuf buffers laid out [slot][per_slot bytes],
+// the first hist bytes of the slot are zeroed, and dec_pos[slot] = 0.
+struct DecResetArgs {
+    int k = 0, nbuf = 0;
+    char* buf[16] = {};
+    long long per_slot[16] = {};
+    int hist[16] = {};
+    int* dec_pos = nullptr;
+    unsigned char slot[64] = {};
+};
+void launch_dec_reset(const DecResetArgs& a, hipStream_t s);
 
 // eos[m] = dot(X[m], w) + b
 void launch_rowdot(const float* X, int ldx, int M, int D, const float* w, const float* b, float* out, hipStream_t s);
@@ -124,7 +158,7 @@ bool resblock_supported(int co, int taps, int wtype);
 void launch_resblock(const ResblockArgs& a, hipStream_t s);
 
 // Carry history: for each b, rows [T, T+H) of buf[b] move to rows [0, H)  (row length C floats).
-void launch_shift_history(float* buf, long long bs, int T, int H, int C, int B, hipStream_t s);
+void launch_shift_history(float* buf, long long bs, int T, int H, int C, int B, hipStream_t s, unsigned long long mask = ~0ull, int slot0 = 0);
 
 // ---- LSD flow head --------------------------------------------------------------------------------
 // All `steps` Euler iterations of the flow MLP for every row:
@@ -170,6 +204,7 @@ void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s);
 size_t flow_ring_workspace_bytes(int B, int blocks);
 size_t flow_ring_ctl_bytes(int B, int blocks);
 size_t flow_ring_err_word(int B, int blocks);
+size_t flow_ring_counter_word();
 void flow_ring_prepare();   // once per device, outside stream capture
 void flow_head_prepare(int C, int wtype);   // once per device, outside stream capture
 // Host-side reorder of a flow-head weight W[N][K] into the fragment-major layout the kernel streams.

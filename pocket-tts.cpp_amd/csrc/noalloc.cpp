@@ -7,8 +7,8 @@
 // later use (kernel arguments) goes through the pointer it got.
 //
 // Every call on one GPU shares that GPU's array and finds the previous call's contents in it.  The only words that
-// must start a call at zero are the persistent head's counters; the call's second launch clears them before the
-// head starts.  Every other area is written in full by the launch that produces it before any launch reads it.  Calls that
+// must start a call at zero are the persistent head's counters, which the call's second launch clears before the
+// head starts, and its error word, whose place moves with the row count and which the call clears first.  Every other area is written in full by the launch that produces it before any launch reads it.  Calls that
 // overlap on one GPU would race on the array; a process-wide mutex per device serialises the calls made through
 // this library.
 #include <mutex>
@@ -59,6 +59,7 @@ void Engine::op_flow_euler_static(const float* cond_dev, const float* x0_dev, in
     FlowScratch fs{reinterpret_cast<float*>(base + off[0]), reinterpret_cast<float*>(base + off[1]),
                    reinterpret_cast<float*>(base + off[2]), reinterpret_cast<float*>(base + off[3]),
                    reinterpret_cast<unsigned*>(base + off[4])};
+    PTTS_HIP(hipMemsetAsync(fs.ctl, 0, 4, stream_));   // the error word: this spot may hold another row count's workspace
     flow_core(fs, stream_, cond_dev, x0_dev, spec().latent, x_out_dev, B, nullptr, 0, nullptr, nullptr, nullptr);
     PTTS_HIP(hipStreamSynchronize(stream_));
     check_flow_ring(fs.ctl, B);

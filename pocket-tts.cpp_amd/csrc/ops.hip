@@ -209,14 +209,17 @@ void launch_attention(const AttentionArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ small helpers
-__global__ void advance_pos_kernel(int* pos, int n, int delta) {
+__global__ void advance_pos_kernel(int* pos, int n, int delta, unsigned long long mask, int slot0) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) pos[i] += delta;
+    if (i < n && (mask == ~0ull || ((mask >> (slot0 + i)) & 1ull))) pos[i] += delta;
 }
-void launch_advance_pos(int* pos, int n, int delta, hipStream_t s) {
+void launch_advance_pos(int* pos, int n, int delta, hipStream_t s, unsigned long long mask, int slot0) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(advance_pos_kernel, dim3((n + 63) / 64), dim3(64), 0, s, pos, n, delta);
+    hipLaunchKernelGGL(advance_pos_kernel, dim3((n + 63) / 64), dim3(64), 0, s, pos, n, delta, mask, slot0);
 }
+
+__global__ void poke_int_kernel(int* p, int v) { *p = v; }
+void launch_poke_int(int* p, int v, hipStream_t s) { hipLaunchKernelGGL(poke_int_kernel, dim3(1), dim3(1), 0, s, p, v); }
 
 __global__ void reset_pos_mask_kernel(int* pos, unsigned long long mask) {
     const int i = threadIdx.x;
@@ -224,6 +227,47 @@ __global__ void reset_pos_mask_kernel(int* pos, unsigned long long mask) {
 }
 void launch_reset_pos_mask(int* pos, unsigned long long mask, hipStream_t s) {
     if (mask) hipLaunchKernelGGL(reset_pos_mask_kernel, dim3(1), dim3(64), 0, s, pos, mask);
+}
+
+// grid (8, 2 * layers, k): block (x, y, i) copies an eighth of one layer's K (y even) or V (y odd) rows of newcomer i;
+// the blocks with y == 0 also fill the newcomer's start-point ring rows, block (0, 0, i) its position and BOS row.
+__global__ __launch_bounds__(256) void admit_kernel(AdmitArgs a) {
+    const int i = blockIdx.z, layer = blockIdx.y >> 1, tid = threadIdx.x;
+    const int slot = a.slot[i];
+    const size_t slot_bytes = static_cast<size_t>(a.cap) * a.row_bytes;
+    const size_t n16 = static_cast<size_t>(a.len[i]) * a.row_bytes / 16;
+    const char* src = ((blockIdx.y & 1) ? a.v_src : a.k_src) + (static_cast<size_t>(layer) * a.src_slots + i) * slot_bytes;
+    char* dst = ((blockIdx.y & 1) ? a.v_dst : a.k_dst) + (static_cast<size_t>(layer) * a.dst_slots + slot) * slot_bytes;
+    for (size_t j = blockIdx.x * 256 + tid; j < n16; j += gridDim.x * 256)
+        reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(src)[j];
+    if (blockIdx.y == 0) {
+        float* ring = a.noise_ring + static_cast<size_t>(slot) * a.ring * a.L;
+        const float* nz = a.noise_stage + static_cast<size_t>(i) * a.frames * a.L;
+        const bool has = a.has_noise[i] != 0;
+        for (int j = blockIdx.x * 256 + tid; j < a.frames * a.L; j += gridDim.x * 256) {
+            const int f = j / a.L, c = j - f * a.L;
+            ring[static_cast<size_t>((a.g0 + f) % a.ring) * a.L + c] = has ? nz[j] : 0.f;
+        }
+        if (blockIdx.x == 0) {
+            if (tid == 0) a.lm_pos[slot] = a.len[i];
+            for (int c = tid; c < a.L; c += 256) a.xcur[static_cast<size_t>(slot) * a.L + c] = a.bos[c];
+        }
+    }
+}
+void launch_admit(const AdmitArgs& a, hipStream_t s) {
+    if (a.k <= 0) return;
+    hipLaunchKernelGGL(admit_kernel, dim3(8, 2 * a.layers, a.k), dim3(256), 0, s, a);
+}
+
+__global__ __launch_bounds__(256) void dec_reset_kernel(DecResetArgs a) {
+    const int bi = blockIdx.x, slot = a.slot[blockIdx.y];
+    unsigned* p = reinterpret_cast<unsigned*>(a.buf[bi] + static_cast<size_t>(slot) * a.per_slot[bi]);
+    for (int j = threadIdx.x; j < a.hist[bi] / 4; j += 256) p[j] = 0u;
+    if (bi == 0 && threadIdx.x == 0) a.dec_pos[slot] = 0;
+}
+void launch_dec_reset(const DecResetArgs& a, hipStream_t s) {
+    if (a.k <= 0 || a.nbuf <= 0) return;
+    hipLaunchKernelGGL(dec_reset_kernel, dim3(a.nbuf, a.k), dim3(256), 0, s, a);
 }
 
 __global__ void gather_latents_kernel(const float* lat, int ring, int slot0, int nb, int start, int n, int L, const float* stdv, const float* mean,
@@ -429,15 +473,17 @@ void launch_conv_from_mono(const float* audio, long long a_bs, const int* len, i
 // One thread per (batch element, channel) walks the H history rows in ascending order, so the copy is
 // a correct forward memmove even when the chunk is shorter than the history (source rows overlap
 // destination rows); threads never share a column.
-__global__ void shift_history_kernel(float* buf, long long bs, int T, int H, int C) {
+__global__ void shift_history_kernel(float* buf, long long bs, int T, int H, int C, unsigned long long mask, int slot0) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (!((mask >> (slot0 + blockIdx.y)) & 1ull)) return;   // this slot's stream does not advance
     float* base = buf + (long long)blockIdx.y * bs;
     for (int h = 0; h < H; ++h) base[(long long)h * C + c] = base[(long long)(T + h) * C + c];
 }
-void launch_shift_history(float* buf, long long bs, int T, int H, int C, int B, hipStream_t s) {
+void launch_shift_history(float* buf, long long bs, int T, int H, int C, int B, hipStream_t s, unsigned long long mask, int slot0) {
     if (H <= 0 || C <= 0 || B <= 0 || T <= 0) return;
-    hipLaunchKernelGGL(shift_history_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, buf, bs, T, H, C);
+    if (slot0 + B > 64 && mask != ~0ull) throw std::runtime_error("shift_history: a slot mask covers 64 slots");
+    hipLaunchKernelGGL(shift_history_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, buf, bs, T, H, C, slot0 + B > 64 ? ~0ull : mask, slot0 + B > 64 ? 0 : slot0);
 }
 
 // cemb is given as `splits` K-slice slabs [splits][B][C] of the conditioning product plus its bias; the slabs are

@@ -2,7 +2,10 @@
 // loadModels() (/root/reference/src/pocket_tts.cpp:89-113); layout is documented in pyhost/ptts_pack.py.
 #include "common.h"
 
+#include <chrono>
+#include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace ptts {
@@ -16,6 +19,25 @@ struct RawEntry {
 static_assert(sizeof(RawEntry) == 120, "pack entry layout");
 constexpr size_t kHeaderSize = 16 + 64 * 4 + 16 * 4;
 }  // namespace
+
+bool trace_on() {
+    static const bool on = std::getenv("POCKET_TTS_TRACE") != nullptr;
+    return on;
+}
+
+void trace_line(const char* what) {
+    if (trace_on()) std::fprintf(stderr, "[pocket-tts] %s\n", what);
+}
+
+void trace_fmt(const char* fmt, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    std::fprintf(stderr, "[pocket-tts %lld.%03lld ms] %s\n", static_cast<long long>(us / 1000 % 100000), static_cast<long long>(us % 1000), buf);
+}
 
 Pack::Pack(const std::string& path) {
     FILE* f = std::fopen(path.c_str(), "rb");

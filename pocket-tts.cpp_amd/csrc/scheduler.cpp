@@ -1,62 +1,745 @@
-// Host scheduler of the single-utterance entry points.
+// Host scheduler: a slot table with refill (continuous batching) behind the single-utterance entry points.
 //
-// The reference serves one utterance per call and is not thread-safe (src/pocket_tts.cpp:548-657 runs on the
-// instance's sessions and state).  Here any number of threads may call generate on one handle; the GPU engine
-// works on lock-step batches, so the calls are coalesced: the first caller that finds no batch in flight becomes
-// the leader, takes everything queued so far (at most kMaxCoalesce utterances) and runs it as one batch; callers
-// that arrive meanwhile queue up and form the next batch.  Nobody waits for a timer: a lone caller runs at once
-// as a batch of one, and under load the batch size grows to whatever accumulates during one batch's run time.
+// The reference serves one utterance per call on one thread (src/pocket_tts.cpp:548-657 offline, :686-979 streaming) and
+// is not thread-safe.  Utterances are independent of each other (every call creates its own state, :563, :710, :737), so
+// here any number of threads may call on one handle and their utterances share the GPU:
+//
+//   * one worker thread per engine steps a table of kSlots utterance slots, one frame of every occupied slot per step
+//     (the same captured frame body as the lock-step batch, launched over the occupied prefix of the table);
+//   * an utterance is prefilled into a staging batch, its KV rows are copied into a free slot and it joins at the next
+//     step.  Offline utterances join at multiples of 15 steps of the table's clock, so that their 15-frame decoder chunks
+//     (:461) fall on the same steps and one decoder call serves all of them; streaming utterances join at multiples of
+//     their chunk size for the same reason once a quarter of the table is taken, and at once below that;
+//   * when an utterance's stop rule fires (:596-603) or it reaches max_frames, its remaining frames are decoded, its slot is
+//     free again, and the next queued utterance takes it: nobody waits for the longest member of a batch;
+//   * decoder chunks are issued per step for the slots that are due, one call per chunk length over the slot range that
+//     holds them; slots inside the range that are not due are computed along and keep their streaming state (due mask);
+//   * PCM leaves through pinned slabs; a second thread per engine waits for each slab's copy and hands the samples to
+//     their owners, so the stepping thread never copies audio; a caller of the streaming API gets its chunks through a
+//     queue and runs its callback on its own thread, as in the reference (src/pocket_tts_c.cpp:183-185).
+//
+// Start points, latents and the EOS rows live in rings indexed by the table's step counter (kept on the device), so the
+// captured frame graph never changes while utterances come and go.
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
 #include "engine.h"
 
 namespace ptts {
 
-void Engine::generate_one(const Utterance& utt, UtteranceResult& out, bool want_latents) {
-    // reject what would fail the whole batch before it can join one
+namespace {
+constexpr int kDecChunk = 15;            // src/pocket_tts.cpp:461
+constexpr float kEosThreshold = -4.0f;   // src/pocket_tts.cpp:596
+constexpr int kSlabs = 8;                // pinned PCM slabs in flight
+constexpr int kWidths[] = {1, 2, 4, 8, 16, 32, 48, 64};   // launch widths of the frame body (occupied prefix, rounded up)
+}  // namespace
+
+struct Engine::Request {
+    Utterance utt;                       // token ids copied; voice / noise memory stays the caller's (it blocks until done)
+    bool want_latents = false;
+    bool streaming = false;
+    int chunk_frames = 0;
+    const std::atomic<bool>* cancel = nullptr;
+    bool poll_cancel = false, want_progress = false;
+    UtteranceResult* out = nullptr;
+    std::vector<float> noise;            // start points drawn at submission (temperature > 0 and none given)
+    // ---- worker side
+    // decoder items not yet handed over: counted by the stepping thread when an item becomes due (before `closed` is
+    // set), counted down by the delivery thread; whoever brings it to zero on a closed request finishes the request
+    std::atomic<int> outstanding{0};
+    std::atomic<bool> closed{false};     // no further decode will be issued
+    std::vector<float> chunk_acc;        // streaming: sub-chunks of one callback's audio (delivery thread only)
+    // ---- shared with the caller (mu)
+    struct Event { int kind = 0; std::vector<float> samples; bool is_final = false; int frame = 0; };   // kind 0: chunk, 1: progress
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Event> events;
+    bool done = false;
+    std::exception_ptr err;
+};
+
+struct Engine::Table {
+    struct Slot {
+        Request* req = nullptr;
+        int g0 = 0, frames = 0, eos_step = -1, decoded = 0, generation = 0;
+    };
+    struct Item { Request* req; int slot, f0, n; bool last_sub, is_final, latents; int lat_frames0, lat_g0; int parity; };
+    struct Delivery { hipEvent_t ev = nullptr; int slab = -1; int slot0 = 0, n = 0; std::vector<Item> items; };
+
+    std::unique_ptr<Batch> b, pb;        // the table's state, and the staging batch prefill passes run in
+    std::array<Slot, kSlots> slots;
+    int occupied = 0;
+    bool graphs_ready = false;
+    float* slabs[kSlabs] = {};           // pinned [kSlots][15 * frame] PCM
+    float* h_lat[2] = {nullptr, nullptr};   // pinned [kSlots][lat_frames][L], by slot generation parity
+    int* h_small = nullptr;                 // pinned [3][kSlots]: voice rows, tokens, lengths of the utterances being admitted
+    // pinned staging of an admission's voice rows, token ids and start points (one upload each instead of one per utterance)
+    float* h_voice = nullptr; size_t h_voice_rows = 0;
+    long long* h_ids = nullptr;
+    float* h_noise = nullptr;
+    DevBuf noise_stage;
+    // ---- shared between the stepping thread and the delivery thread (d_mu)
+    std::mutex d_mu;
+    std::condition_variable d_cv;
+    std::deque<Delivery> deliveries;
+    int in_flight = 0;                   // deliveries popped by the delivery thread and not yet handed over
+    bool slab_busy[kSlabs] = {};
+    std::vector<hipEvent_t> free_events;
+    bool d_stop = false;
+    std::exception_ptr d_err;            // a HIP failure seen by the delivery thread
+    // the requests of this step's decoder items, in issue order, and how many of them have reached `deliveries`
+    std::vector<Request*> due_reqs;
+    size_t due_pushed = 0;
+    std::thread d_thread;
+    int fs = 0, R = 0, L = 0, device = 0;
+
+    void deliver_main();
+    static void finish(Request* r, std::exception_ptr err = nullptr) {
+        std::lock_guard<std::mutex> lk(r->mu);
+        if (err && !r->err) r->err = err;
+        r->done = true;
+        r->cv.notify_all();
+    }
+    ~Table() {
+        {
+            std::lock_guard<std::mutex> lk(d_mu);
+            d_stop = true;
+            d_cv.notify_all();
+        }
+        if (d_thread.joinable()) d_thread.join();
+        for (auto& s : slabs) if (s) (void)hipHostFree(s);
+        for (auto& p : h_lat) if (p) (void)hipHostFree(p);
+        if (h_small) (void)hipHostFree(h_small);
+        if (h_voice) (void)hipHostFree(h_voice);
+        if (h_ids) (void)hipHostFree(h_ids);
+        if (h_noise) (void)hipHostFree(h_noise);
+        for (auto& d : deliveries) if (d.ev) (void)hipEventDestroy(d.ev);
+        for (auto& e : free_events) (void)hipEventDestroy(e);
+    }
+};
+
+// Completed deliveries, oldest first: PCM from the pinned slab to its owner (result vector or streaming chunk).
+void Engine::Table::deliver_main() {
+    (void)hipSetDevice(device);
+    for (;;) {
+        Delivery d;
+        {
+            std::unique_lock<std::mutex> lk(d_mu);
+            d_cv.wait(lk, [&] { return d_stop || !deliveries.empty(); });
+            if (deliveries.empty()) return;   // stopping, nothing left
+            d = std::move(deliveries.front());
+            deliveries.pop_front();
+            ++in_flight;
+        }
+        std::exception_ptr err;
+        const hipError_t e = hipEventSynchronize(d.ev);
+        if (e != hipSuccess) err = std::make_exception_ptr(std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " while waiting for a decoder chunk"));
+        PTTS_TRACEF("delivery: %d frames, %d items", d.n, static_cast<int>(d.items.size()));
+        for (auto& it : d.items) {
+            Request* r = it.req;
+            if (!err && it.n > 0) {
+                const float* src = slabs[d.slab] + static_cast<size_t>(it.slot - d.slot0) * d.n * fs;
+                if (!r->streaming) {
+                    std::vector<float>& a = r->out->audio;
+                    if (a.size() < static_cast<size_t>(it.f0 + it.n) * fs) a.resize(static_cast<size_t>(it.f0 + it.n) * fs);
+                    std::memcpy(a.data() + static_cast<size_t>(it.f0) * fs, src, static_cast<size_t>(it.n) * fs * 4);
+                } else {
+                    r->chunk_acc.insert(r->chunk_acc.end(), src, src + static_cast<size_t>(it.n) * fs);
+                    if (it.last_sub) {
+                        Request::Event ev;
+                        ev.samples.swap(r->chunk_acc);
+                        ev.is_final = it.is_final;
+                        std::lock_guard<std::mutex> lk(r->mu);
+                        r->events.push_back(std::move(ev));
+                        r->cv.notify_all();
+                    }
+                }
+            }
+            if (!err && it.latents) {
+                const float* hl = h_lat[it.parity] + static_cast<size_t>(it.slot) * R * L;
+                r->out->latents.resize(static_cast<size_t>(it.lat_frames0) * L);
+                for (int f = 0; f < it.lat_frames0; ++f)
+                    std::memcpy(r->out->latents.data() + static_cast<size_t>(f) * L, hl + static_cast<size_t>((it.lat_g0 + f) % R) * L, static_cast<size_t>(L) * 4);
+            }
+            if (err) {
+                // the request fails once, at its last item; its earlier items are dropped
+                std::lock_guard<std::mutex> lk(r->mu);
+                if (!r->err) r->err = err;
+            }
+            if (r->outstanding.fetch_sub(1) == 1 && r->closed.load()) finish(r);
+        }
+        std::lock_guard<std::mutex> lk(d_mu);
+        if (err && !d_err) d_err = err;
+        if (d.slab >= 0) slab_busy[d.slab] = false;
+        free_events.push_back(d.ev);
+        --in_flight;
+        d_cv.notify_all();
+    }
+}
+
+void Engine::validate_request(const Utterance& utt) const {
     if (utt.token_ids.empty()) throw std::runtime_error("Text cannot be empty");
     if (static_cast<int>(utt.token_ids.size()) > opt_.max_text_tokens) throw std::runtime_error("text has more tokens than the engine was sized for");
     if (utt.voice_frames < 0 || (utt.voice_frames > 0 && !utt.voice)) throw std::runtime_error("voice rows missing");
+    // the same capacity every Batch is built with (voice + text + frames, and room for a finished slot's idle steps)
+    int cap = 64 + opt_.max_text_tokens + opt_.max_frames + 8;
+    cap = (cap + 63) / 64 * 64;
+    const long long need = static_cast<long long>(utt.voice_frames) + static_cast<long long>(utt.token_ids.size());
+    if (need + opt_.max_frames > cap || need > cap)
+        throw std::runtime_error("LM context exceeds the KV-cache capacity (voice + text + frames too long)");
+}
 
-    Pending me{&utt, &out, want_latents, nullptr, false};
-    std::unique_lock<std::mutex> lk(q_mu_);
-    queue_.push_back(&me);
-    while (!me.done) {
-        if (leader_active_) {
-            q_cv_.wait(lk);
+void Engine::submit(Request& r) {
+    Request* one = &r;
+    submit_all(&one, 1);
+}
+
+// Validates and prepares every request, then queues them all at once (a burst joins the table in one admission).
+void Engine::submit_all(Request* const* reqs, size_t n) {
+    for (size_t i = 0; i < n; ++i) validate_request(reqs[i]->utt);   // fail before anything is queued
+    PTTS_TRACEF("submit: %d (%s)", static_cast<int>(n), n && reqs[0]->streaming ? "stream" : "offline");
+    for (size_t i = 0; i < n; ++i) {
+        Request& r = *reqs[i];
+        if (r.utt.noise || !(opt_.temperature > 0)) continue;
+        // N(0, sqrt(T)) from a fresh distribution object per frame (src/pocket_tts.cpp:606-613), drawn up front
+        const int L = spec().latent;
+        r.noise.resize(static_cast<size_t>(opt_.max_frames) * L);
+        std::mt19937 gen;
+        {
+            std::lock_guard<std::mutex> lk(q_mu_);
+            gen.seed(rng_());
+        }
+        for (int f = 0; f < opt_.max_frames; ++f) {
+            std::normal_distribution<float> dist(0.0f, std::sqrt(opt_.temperature));
+            for (int k = 0; k < L; ++k) r.noise[static_cast<size_t>(f) * L + k] = dist(gen);
+        }
+    }
+    std::lock_guard<std::mutex> lk(q_mu_);
+    if (worker_stop_) throw std::runtime_error("engine is shutting down");
+    if (!worker_started_) {
+        worker_started_ = true;
+        worker_ = std::thread([this] { worker_main(); });
+    }
+    for (size_t i = 0; i < n; ++i) queue_.push_back(reqs[i]);
+    q_cv_.notify_all();
+}
+
+void Engine::generate_one(const Utterance& utt, UtteranceResult& out, bool want_latents) {
+    Request r;
+    r.utt = utt;
+    r.want_latents = want_latents;
+    r.out = &out;
+    out = UtteranceResult();
+    submit(r);
+    std::unique_lock<std::mutex> lk(r.mu);
+    r.cv.wait(lk, [&] { return r.done; });
+    if (r.err) std::rethrow_exception(r.err);
+}
+
+void Engine::generate_queue(const std::vector<Utterance>& utts, std::vector<UtteranceResult>& out, bool want_latents) {
+    out.assign(utts.size(), UtteranceResult());
+    std::vector<std::unique_ptr<Request>> reqs;
+    std::vector<Request*> ptrs;
+    for (size_t i = 0; i < utts.size(); ++i) {
+        reqs.emplace_back(new Request());
+        reqs.back()->utt = utts[i];
+        reqs.back()->want_latents = want_latents;
+        reqs.back()->out = &out[i];
+        ptrs.push_back(reqs.back().get());
+    }
+    if (ptrs.empty()) return;
+    submit_all(ptrs.data(), ptrs.size());
+    std::exception_ptr first;
+    for (auto& r : reqs) {
+        std::unique_lock<std::mutex> lk(r->mu);
+        r->cv.wait(lk, [&] { return r->done; });
+        if (r->err && !first) first = r->err;
+    }
+    if (first) std::rethrow_exception(first);
+}
+
+int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const ChunkCallback& cb, const std::atomic<bool>* cancel_flag,
+                               bool poll_cancel, const std::function<void(int)>& progress, UtteranceResult* capture) {
+    if (!cb) throw std::invalid_argument("Callback must be provided");   // src/pocket_tts.cpp:693-695
+    if (std::getenv("POCKET_TTS_INLINE_STREAMING")) return generate_streaming_inline(utt, chunk_frames, cb, cancel_flag, poll_cancel, progress, capture);
+    if (chunk_frames <= 0) chunk_frames = 1;
+    Request r;
+    UtteranceResult local;
+    r.utt = utt;
+    r.streaming = true;
+    r.chunk_frames = chunk_frames;
+    r.cancel = cancel_flag;
+    r.poll_cancel = poll_cancel;
+    r.want_progress = static_cast<bool>(progress);
+    r.want_latents = capture != nullptr;
+    r.out = capture ? capture : &local;
+    *r.out = UtteranceResult();
+    submit(r);
+    int total = 0;
+    bool stopped = false;
+    for (;;) {
+        Request::Event ev;
+        {
+            std::unique_lock<std::mutex> lk(r.mu);
+            r.cv.wait(lk, [&] { return r.done || !r.events.empty(); });
+            if (r.events.empty()) break;   // done and drained
+            ev = std::move(r.events.front());
+            r.events.pop_front();
+        }
+        if (ev.kind == 1) {
+            if (!stopped && progress) progress(ev.frame);                                  // :891-893
             continue;
         }
-        leader_active_ = true;
-        std::vector<Pending*> batch;
-        while (!queue_.empty() && batch.size() < kMaxCoalesce) {
-            batch.push_back(queue_.front());
-            queue_.pop_front();
-        }
-        lk.unlock();
-        std::exception_ptr err;
-        try {
-            std::vector<Utterance> utts;
-            bool want = false;
-            for (Pending* p : batch) { utts.push_back(*p->utt); want = want || p->want_latents; }
-            std::vector<UtteranceResult> res;
-            generate(utts, res, want);
-            for (size_t i = 0; i < batch.size(); ++i) *batch[i]->out = std::move(res[i]);
-        } catch (...) {
-            err = std::current_exception();
-        }
-        lk.lock();
-        for (Pending* p : batch) { p->err = err; p->done = true; }
-        sched_stats_.batches += 1;
-        sched_stats_.utterances += static_cast<long>(batch.size());
-        sched_stats_.largest = std::max(sched_stats_.largest, static_cast<long>(batch.size()));
-        leader_active_ = false;
-        q_cv_.notify_all();
+        // a cancel request ends the stream at the next frame when polling is on (:745-750) and always drops the tail flush (:897)
+        const bool cancelled = cancel_flag && cancel_flag->load();
+        if (stopped || (cancelled && (poll_cancel || ev.is_final))) { stopped = true; continue; }
+        if (capture) capture->audio.insert(capture->audio.end(), ev.samples.begin(), ev.samples.end());
+        cb(ev.samples.data(), static_cast<int>(ev.samples.size()), ev.is_final);
+        total += static_cast<int>(ev.samples.size());
     }
-    lk.unlock();
-    if (me.err) std::rethrow_exception(me.err);
+    if (r.err) std::rethrow_exception(r.err);
+    return total;
 }
 
 Engine::SchedulerStats Engine::scheduler_stats() {
     std::lock_guard<std::mutex> lk(q_mu_);
     return sched_stats_;
+}
+
+void Engine::stop_worker() {
+    {
+        std::lock_guard<std::mutex> lk(q_mu_);
+        worker_stop_ = true;
+        q_cv_.notify_all();
+    }
+    if (worker_.joinable()) worker_.join();
+}
+
+void Engine::drop_table() { delete table_; table_ = nullptr; }
+
+void Engine::worker_main() {
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(q_mu_);
+            q_cv_.wait(lk, [&] { return worker_stop_ || !queue_.empty(); });
+            if (worker_stop_ && queue_.empty()) return;
+        }
+        try {
+            PTTS_TRACE("worker: activation wanted");
+            std::lock_guard<std::recursive_mutex> call(call_mu_);   // a lock-step generate() and the table take turns
+            PTTS_TRACE("worker: activation begins");
+            run_table();
+            PTTS_TRACE("worker: activation ended");
+        } catch (...) {
+            PTTS_TRACE("worker: activation failed");
+            // a failure of the table itself (a HIP error): everyone waiting learns of it
+            const std::exception_ptr err = std::current_exception();
+            std::vector<Request*> victims;
+            {
+                std::lock_guard<std::mutex> lk(q_mu_);
+                victims.assign(queue_.begin(), queue_.end());
+                queue_.clear();
+            }
+            if (table_) {
+                Table& T = *table_;
+                {   // what the decoder stream still owes is handed over (or failed) by the delivery thread first
+                    std::unique_lock<std::mutex> lk(T.d_mu);
+                    T.d_cv.wait(lk, [&] { return T.deliveries.empty() && T.in_flight == 0; });
+                }
+                // left over: utterances still in a slot, and those with decoder items that were never issued; neither can
+                // have been finished by the delivery thread
+                for (size_t j = T.due_pushed; j < T.due_reqs.size(); ++j)
+                    if (std::find(victims.begin(), victims.end(), T.due_reqs[j]) == victims.end()) victims.push_back(T.due_reqs[j]);
+                for (auto& sl : T.slots)
+                    if (sl.req) {
+                        if (std::find(victims.begin(), victims.end(), sl.req) == victims.end()) victims.push_back(sl.req);
+                        sl.req = nullptr;
+                    }
+                (void)hipDeviceSynchronize();
+                drop_table();
+            }
+            for (Request* r : victims) Table::finish(r, err);
+        }
+    }
+}
+
+// One activation of the table: from the first queued utterance until the table and the queue are empty.
+void Engine::run_table() {
+    const Spec& s = spec();
+    const int L = s.latent, D = s.d_model, fs = s.frame_size(), F = opt_.max_frames;
+    std::unique_lock<std::mutex> gpu(mu_);
+    PTTS_HIP(hipSetDevice(opt_.device));
+    if (!table_) {
+        table_ = new Table();
+        Table& N = *table_;
+        N.b = std::make_unique<Batch>(*this, kSlots);
+        N.pb = std::make_unique<Batch>(*this, kSlots, true);
+        N.fs = fs; N.R = N.b->lat_frames; N.L = L; N.device = opt_.device;
+        for (auto& p : N.slabs) PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), static_cast<size_t>(kSlots) * kDecChunk * fs * 4));
+        for (auto& p : N.h_lat) PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), static_cast<size_t>(kSlots) * N.R * L * 4));
+        N.b->noise_all.alloc(static_cast<size_t>(kSlots) * N.R * L * 4);
+        N.noise_stage.alloc(static_cast<size_t>(kSlots) * F * L * 4);
+        PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&N.h_small), static_cast<size_t>(3) * kSlots * 4));
+        PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&N.h_ids), static_cast<size_t>(kSlots) * opt_.max_text_tokens * 8));
+        PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&N.h_noise), static_cast<size_t>(kSlots) * F * L * 4));
+        N.pb->ids_stage.alloc(static_cast<size_t>(kSlots) * opt_.max_text_tokens * 8);
+        N.d_thread = std::thread([&N] { N.deliver_main(); });
+    }
+    Table& T = *table_;
+    Batch& b = *T.b;
+    Batch& pb = *T.pb;
+    hipStream_t st = stream_, dst = dec_stream_;
+    b.st = st; b.dec_st = dst; b.ready = latents_ready_;
+    pb.st = st; pb.dec_st = st;
+    const int R = b.lat_frames;
+    b.step_ring = R;
+    b.eos_ring = std::max(F, 16);
+    b.x0_src = b.noise_all.f(); b.x0_stride = static_cast<long long>(R) * L; b.x0_step_stride = L;
+    // positions and the step counter start at zero; the decoder histories of a slot are cleared when an utterance takes it
+    PTTS_HIP(hipMemsetAsync(b.lm_pos.p, 0, b.lm_pos.bytes, st));
+    PTTS_HIP(hipMemsetAsync(b.dec_pos.p, 0, b.dec_pos.bytes, st));
+    std::fill(b.dec_pos_host.begin(), b.dec_pos_host.end(), 0);
+    PTTS_HIP(hipMemsetAsync(b.step_dev.p, 0, 4, st));
+    PTTS_HIP(hipMemsetAsync(b.xcur.p, 0, b.xcur.bytes, st));
+    PTTS_HIP(hipStreamSynchronize(dst));
+    *b.h_flag = 0;
+    for (auto& sl : T.slots) { sl.req = nullptr; }
+    T.occupied = 0;
+    T.due_reqs.clear(); T.due_pushed = 0;
+    if (!bos_row_.p) {
+        bos_row_.alloc(static_cast<size_t>(L) * 4);
+        std::vector<float> nanrow(L, std::numeric_limits<float>::quiet_NaN());
+        PTTS_HIP(hipMemcpyAsync(b.seq_in.p, nanrow.data(), static_cast<size_t>(L) * 4, hipMemcpyHostToDevice, st));
+        launch_prep_latent(b.seq_in.f(), bos_row_.f(), 1, L, 0, hd_.bos, nullptr, st);   // NaN marker -> BOS embedding (:579)
+        PTTS_HIP(hipStreamSynchronize(st));
+    }
+    const bool graph = use_graph_ && !timing_;
+    const size_t kvb = b.kv16 ? 2 : 4;
+    if (graph && !T.graphs_ready) {
+        // every launch width's frame graph now, so that no caller's first chunk pays for a capture later
+        for (int w : kWidths) { b.Bw = w; (void)ensure_frame_graph(b); }
+        T.graphs_ready = true;
+    }
+    {
+        std::lock_guard<std::mutex> lk(q_mu_);
+        sched_stats_.batches += 1;
+    }
+    // the decoder's streaming state: the rows in front of each chunk area are all that carries over from chunk to chunk
+    DecResetArgs dr;
+    {
+        const int M = s.mimi_dim, U = s.upsample, T0max = kDecChunk * U;
+        auto add = [&](DevBuf& buf, size_t per_slot_bytes, size_t hist_bytes) {
+            dr.buf[dr.nbuf] = static_cast<char*>(buf.p); dr.per_slot[dr.nbuf] = static_cast<long long>(per_slot_bytes);
+            dr.hist[dr.nbuf] = static_cast<int>(hist_bytes); ++dr.nbuf;
+        };
+        add(b.qbuf, static_cast<size_t>(1 + kDecChunk) * M * 4, static_cast<size_t>(M) * 4);
+        add(b.ybuf, static_cast<size_t>(s.kernel - 1 + T0max) * M * 4, static_cast<size_t>(s.kernel - 1) * M * 4);
+        int c = 8 * s.n_filters, Tm = T0max;
+        add(b.e0buf, static_cast<size_t>(1 + Tm) * c * 4, static_cast<size_t>(c) * 4);
+        for (int j = 0; j < 3; ++j) {
+            const int co = c / 2, hn = j < 2 ? 1 : s.last_kernel - 1;
+            Tm *= s.ratios[j];
+            const size_t esz = dec_fused_[j] ? 2 : 4;   // a fused stage keeps bf16 rows in these buffers
+            add(b.uebuf[j], static_cast<size_t>(s.res_kernel - 1 + Tm) * co * esz, static_cast<size_t>(s.res_kernel - 1) * co * esz);
+            add(b.ebuf[j], static_cast<size_t>(hn + Tm) * co * esz, static_cast<size_t>(hn) * co * esz);
+            c = co;
+        }
+        dr.dec_pos = b.dec_pos.as<int>();
+    }
+
+    auto get_event = [&]() {
+        hipEvent_t e = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(T.d_mu);
+            if (!T.free_events.empty()) { e = T.free_events.back(); T.free_events.pop_back(); }
+        }
+        if (!e) PTTS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return e;
+    };
+    auto take_slab = [&]() {
+        std::unique_lock<std::mutex> lk(T.d_mu);
+        for (;;) {
+            for (int i = 0; i < kSlabs; ++i)
+                if (!T.slab_busy[i]) { T.slab_busy[i] = true; return i; }
+            T.d_cv.wait(lk);
+        }
+    };
+
+    int gather_us = 100;
+    if (const char* e = std::getenv("POCKET_TTS_GATHER_US")) gather_us = std::max(0, std::atoi(e));
+    int gs = 0;   // the table's clock: frame steps launched so far
+    for (;;) {
+        // ---- admission
+        std::vector<Request*> incoming;
+        {
+            std::unique_lock<std::mutex> lk(q_mu_);
+            if (T.occupied == 0 && gather_us > 0) {
+                // an idle table waits a moment for the rest of a burst: callers that arrive together then share one prefill
+                // pass and one chunk phase instead of trailing each other by a step (POCKET_TTS_GATHER_US, default 100)
+                const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(4 * gather_us);
+                for (size_t seen = queue_.size(); seen < static_cast<size_t>(kSlots) && std::chrono::steady_clock::now() < t_end;) {
+                    q_cv_.wait_for(lk, std::chrono::microseconds(gather_us));
+                    if (queue_.size() == seen) break;
+                    seen = queue_.size();
+                }
+            }
+            int free_slots = kSlots - T.occupied;
+            for (auto it = queue_.begin(); it != queue_.end() && free_slots > 0;) {
+                Request* r = *it;
+                // a stream joins at once while the table is lightly loaded (first-chunk latency; its chunks then fall on steps
+                // of their own and cost decoder calls of their own), on a chunk boundary of the clock once it is not
+                const int period = r->streaming ? (T.occupied < kSlots / 4 ? 1 : std::min(r->chunk_frames, kDecChunk)) : kDecChunk;
+                if (T.occupied == 0 || gs % period == 0) {
+                    incoming.push_back(r);
+                    it = queue_.erase(it);
+                    --free_slots;
+                } else {
+                    ++it;
+                }
+            }
+        }
+        if (!incoming.empty()) {
+            const int k = static_cast<int>(incoming.size());
+            PTTS_TRACEF("step %d: %d admitted (%d in the table)", gs, k, T.occupied);
+            // Prefill of all newcomers in one causal pass over [voice; text] each (the reference's two passes, :572 and :575,
+            // write the same cache), padded to the longest, in the staging batch.  Inputs are gathered in pinned memory and
+            // uploaded once; the previous admission's uploads out of these pinned arrays ran before the step whose EOS row
+            // has since arrived.
+            int vmax = 1, rpb = 1;
+            int *nv = T.h_small, *nt = T.h_small + kSlots, *len = T.h_small + 2 * kSlots;
+            for (int i = 0; i < k; ++i) {
+                nv[i] = incoming[i]->utt.voice_frames; nt[i] = static_cast<int>(incoming[i]->utt.token_ids.size());
+                len[i] = nv[i] + nt[i];
+                vmax = std::max(vmax, nv[i]); rpb = std::max(rpb, len[i]);
+            }
+            if (T.h_voice_rows < static_cast<size_t>(vmax)) {
+                if (T.h_voice) { PTTS_HIP(hipStreamSynchronize(st)); PTTS_HIP(hipHostFree(T.h_voice)); T.h_voice = nullptr; }
+                PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&T.h_voice), static_cast<size_t>(kSlots) * vmax * D * 4));
+                T.h_voice_rows = static_cast<size_t>(vmax);
+                pb.voice_stage.alloc(static_cast<size_t>(kSlots) * vmax * D * 4);
+            }
+            AdmitArgs aa;
+            bool any_noise = false;
+            for (int i = 0; i < k; ++i) {
+                const Request* r = incoming[i];
+                const Utterance& u = r->utt;
+                if (nv[i]) std::memcpy(T.h_voice + static_cast<size_t>(i) * vmax * D, u.voice, static_cast<size_t>(nv[i]) * D * 4);
+                std::memcpy(T.h_ids + static_cast<size_t>(i) * opt_.max_text_tokens, u.token_ids.data(), static_cast<size_t>(nt[i]) * 8);
+                // start points of frames 0..: explicit ones, drawn ones, or zeros (temperature 0, :606-613)
+                const float* nz = u.noise ? u.noise : (r->noise.empty() ? nullptr : r->noise.data());
+                aa.has_noise[i] = nz ? 1 : 0;
+                if (nz) { std::memcpy(T.h_noise + static_cast<size_t>(i) * F * L, nz, static_cast<size_t>(F) * L * 4); any_noise = true; }
+            }
+            PTTS_HIP(hipMemcpyAsync(pb.voice_stage.p, T.h_voice, static_cast<size_t>(k) * vmax * D * 4, hipMemcpyHostToDevice, st));
+            PTTS_HIP(hipMemcpyAsync(pb.ids_stage.p, T.h_ids, static_cast<size_t>(k) * opt_.max_text_tokens * 8, hipMemcpyHostToDevice, st));
+            if (any_noise) PTTS_HIP(hipMemcpyAsync(T.noise_stage.p, T.h_noise, static_cast<size_t>(k) * F * L * 4, hipMemcpyHostToDevice, st));
+            PTTS_HIP(hipMemcpyAsync(pb.st_nv.p, nv, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, st));
+            PTTS_HIP(hipMemcpyAsync(pb.st_nt.p, nt, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, st));
+            PTTS_HIP(hipMemcpyAsync(pb.st_len.p, len, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, st));
+            PTTS_HIP(hipMemsetAsync(pb.lm_pos.p, 0, pb.lm_pos.bytes, st));
+            std::fill(pb.lm_pos_host.begin(), pb.lm_pos_host.end(), 0);
+            pb.ensure_rows(static_cast<size_t>(k) * rpb, D, s.lm_ffn);
+            launch_assemble_prefill(pb.voice_stage.f(), static_cast<long long>(vmax) * D, pb.ids_stage.as<long long>(), opt_.max_text_tokens,
+                                    pb.st_nv.as<int>(), pb.st_nt.as<int>(), hd_.text_embed, s.vocab + 1, D, rpb, k, pb.x.f(), st);
+            lm_rows(pb, 0, k, rpb, pb.x.f(), pb.st_len.as<int>(), len);
+            // one launch moves every newcomer into its slot (KV rows, position, BOS row, start points); a second one, on the
+            // decoder stream behind whatever it still has queued for the slots' previous occupants, clears their decoder
+            // state (the reference zero-initialises every state tensor, :133-186)
+            int next_free = 0;
+            for (int i = 0; i < k; ++i) {
+                while (T.slots[next_free].req) ++next_free;
+                Table::Slot& S = T.slots[next_free];
+                S.req = incoming[i]; S.g0 = gs; S.frames = 0; S.eos_step = -1; S.decoded = 0; S.generation += 1;
+                ++T.occupied;
+                aa.slot[i] = static_cast<unsigned char>(next_free); aa.len[i] = len[i];
+                dr.slot[i] = static_cast<unsigned char>(next_free);
+                b.dec_pos_host[next_free] = 0;
+            }
+            aa.k = k; aa.layers = s.lm_layers; aa.row_bytes = static_cast<int>(D * kvb); aa.cap = b.lm_cap; aa.dst_slots = b.B; aa.src_slots = pb.B;
+            aa.k_dst = static_cast<char*>(b.lm_k.p); aa.v_dst = static_cast<char*>(b.lm_v.p);
+            aa.k_src = static_cast<const char*>(pb.lm_k.p); aa.v_src = static_cast<const char*>(pb.lm_v.p);
+            aa.lm_pos = b.lm_pos.as<int>(); aa.xcur = b.xcur.f(); aa.bos = bos_row_.f(); aa.L = L; aa.ring = R; aa.frames = F; aa.g0 = gs;
+            aa.noise_ring = b.noise_all.f(); aa.noise_stage = T.noise_stage.f();
+            launch_admit(aa, st);
+            dr.k = k;
+            launch_dec_reset(dr, dst);
+            check_launches("the admission");
+            std::lock_guard<std::mutex> lk(q_mu_);
+            sched_stats_.admissions += 1;
+            sched_stats_.utterances += k;
+            sched_stats_.largest = std::max(sched_stats_.largest, static_cast<long>(T.occupied));
+        }
+        if (T.occupied == 0) {
+            std::lock_guard<std::mutex> lk(q_mu_);
+            if (queue_.empty()) break;
+            continue;   // something queued that waits for a boundary of an empty table: cannot happen, but never spin on it
+        }
+        // ---- launch width: the occupied prefix, rounded up to a few sizes so that few graphs exist
+        int top = 0;
+        unsigned long long idle_mask = 0;
+        for (int i = 0; i < kSlots; ++i) if (T.slots[i].req) top = i + 1;
+        int width = 1;
+        for (int w : kWidths) if (w >= top) { width = w; break; }
+        for (int i = 0; i < width; ++i) if (!T.slots[i].req) idle_mask |= 1ull << i;
+        // slots that step without an utterance restart at position 0 now and then, so that they never leave their cache
+        if (idle_mask && gs % 8 == 0) launch_reset_pos_mask(b.lm_pos.as<int>(), idle_mask, st);
+        if (b.Bw != width) b.Bw = width;
+        if (graph) {
+            hipGraphExec_t* exec = ensure_frame_graph(b);
+            PTTS_HIP(hipGraphLaunch(exec[gs & 1], st));
+        } else {
+            frame_body(b, gs & 1);
+        }
+        gpu.unlock();
+        // ---- the EOS logits of this step (the flow head of the step is still running when they arrive)
+        for (unsigned spins = 1; __atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < gs + 1; ++spins) {
+            if ((spins & 0x3ff) == 0) {
+                gpu.lock();
+                const bool idle = hipStreamQuery(st) == hipSuccess;
+                if (!idle) (void)hipGetLastError();
+                gpu.unlock();
+                if (idle && __atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < gs + 1) throw std::runtime_error("frame finished without publishing its EOS logits");
+                std::this_thread::yield();
+            }
+        }
+        gpu.lock();
+        const float* e_now = b.h_eos_all + static_cast<size_t>(gs % b.eos_ring) * b.B;
+        struct Due { Request* req; int slot, n, f0, gstart; bool last_sub, is_final, closes; int g0, generation; };
+        std::vector<Due> due;
+        long frames_now = 0;
+        for (int i = 0; i < width; ++i) {
+            Table::Slot& S = T.slots[i];
+            Request* r = S.req;
+            if (!r) continue;
+            const int k = gs - S.g0;          // this slot's own step
+            const float e = e_now[i];
+            if (r->want_latents) r->out->eos.push_back(e);
+            bool stop = false, cancelled = false;
+            if (e > kEosThreshold && S.eos_step < 0) S.eos_step = k;                           // :596
+            if (S.eos_step >= 0 && k >= S.eos_step + opt_.frames_after_eos) stop = true;       // :601 (this step's flow output is not used)
+            if (!stop && r->streaming && r->poll_cancel && r->cancel && r->cancel->load()) { stop = true; cancelled = true; }   // :745-750
+            if (!stop) {
+                S.frames = k + 1;
+                ++frames_now;
+                if (r->want_progress) {
+                    Request::Event ev;
+                    ev.kind = 1; ev.frame = k + 1;
+                    std::lock_guard<std::mutex> lk(r->mu);
+                    r->events.push_back(std::move(ev));
+                    r->cv.notify_all();
+                }
+                if (S.frames >= F) stop = true;
+            }
+            const int pending = S.frames - S.decoded;
+            const size_t first_due = due.size();
+            if (cancelled || (stop && r->streaming && r->cancel && r->cancel->load())) {
+                // a cancelled stream gets no tail flush (:897)
+            } else if (r->streaming) {
+                if (pending > 0 && (stop || pending >= r->chunk_frames)) {                    // :790; tail flush :897-965
+                    // a full chunk is an ordinary flush even when it is the last one; is_final comes only with the tail
+                    // flush of a remainder (:879 is unreachable in the reference, :897-965 is what delivers it)
+                    const bool tail = pending < r->chunk_frames;
+                    for (int f0 = 0; f0 < pending; f0 += kDecChunk) {                          // sub-chunks of <= 15 frames (:796)
+                        const int n = std::min(kDecChunk, pending - f0);
+                        due.push_back({r, i, n, S.decoded + f0, S.g0 + S.decoded + f0, f0 + n == pending, tail, false, S.g0, S.generation});
+                    }
+                    S.decoded = S.frames;
+                }
+            } else if (pending > 0 && (stop || pending == kDecChunk)) {
+                due.push_back({r, i, pending, S.decoded, S.g0 + S.decoded, true, false, false, S.g0, S.generation});
+                S.decoded = S.frames;
+            }
+            if (stop) {
+                r->out->frames = S.frames;
+                // nothing left to decode: the request closes through an item without audio (ordered behind its earlier chunks)
+                if (due.size() == first_due) due.push_back({r, i, 0, S.frames, gs + 1, true, false, false, S.g0, S.generation});
+                due.back().closes = true;
+                // every item of the request is counted before it is marked closed: the delivery thread finishes a closed
+                // request when the count reaches zero
+                r->outstanding.fetch_add(static_cast<int>(due.size() - first_due));
+                r->closed.store(true);
+                S.req = nullptr;
+                --T.occupied;
+                launch_poke_int(b.lm_pos.as<int>() + i, 0, st);   // the slot idles from position 0 until it is taken again
+            } else if (due.size() != first_due) {
+                r->outstanding.fetch_add(static_cast<int>(due.size() - first_due));
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(q_mu_);
+            sched_stats_.frame_steps += 1;
+            sched_stats_.slot_steps += width;
+            sched_stats_.frames += frames_now;
+        }
+        // ---- decoder chunks of this step: one call per (chunk length, ring position) over the slot range that holds the due
+        // slots, in order of ring position, which keeps the sub-chunks of one streaming flush in order
+        if (!due.empty()) {
+            std::stable_sort(due.begin(), due.end(), [](const Due& x, const Due& y) { return x.gstart != y.gstart ? x.gstart < y.gstart : x.n < y.n; });
+            T.due_reqs.clear();
+            for (auto& q : due) T.due_reqs.push_back(q.req);
+            T.due_pushed = 0;
+            PTTS_HIP(hipEventRecord(b.ready, st));
+            PTTS_HIP(hipStreamWaitEvent(dst, b.ready, 0));
+            for (size_t a0 = 0; a0 < due.size();) {
+                size_t a1 = a0;
+                while (a1 < due.size() && due[a1].gstart == due[a0].gstart && due[a1].n == due[a0].n) ++a1;
+                const int n = due[a0].n;
+                Table::Delivery dv;
+                dv.n = n;
+                unsigned long long mask = 0;
+                int lo = kSlots, hi = -1;
+                for (size_t j = a0; j < a1; ++j) { mask |= 1ull << due[j].slot; lo = std::min(lo, due[j].slot); hi = std::max(hi, due[j].slot); }
+                dv.slot0 = lo;
+                if (n > 0) {
+                    gpu.unlock();
+                    dv.slab = take_slab();   // may wait for the delivery thread
+                    gpu.lock();
+                    float* chunk = b.audio.f() + static_cast<size_t>(lo) * kDecChunk * fs;
+                    mimi_decode_dev(b, nullptr, 0, n, chunk, static_cast<long long>(kDecChunk) * fs, dst, lo, hi - lo + 1, due[a0].gstart % R, mask);
+                    PTTS_HIP(hipMemcpy2DAsync(T.slabs[dv.slab], static_cast<size_t>(n) * fs * 4, chunk, static_cast<size_t>(kDecChunk) * fs * 4,
+                                              static_cast<size_t>(n) * fs * 4, hi - lo + 1, hipMemcpyDeviceToHost, dst));
+                    std::lock_guard<std::mutex> lk(q_mu_);
+                    sched_stats_.decode_calls += 1;
+                }
+                for (size_t j = a0; j < a1; ++j) {
+                    const Due& q = due[j];
+                    Table::Item it{q.req, q.slot, q.f0, q.n, q.last_sub, q.is_final, false, 0, 0, q.generation & 1};
+                    if (q.closes && q.req->want_latents) {
+                        // the slot's whole latent ring; the rows of this utterance are picked out when the copy has landed
+                        it.latents = true; it.lat_frames0 = q.req->out->frames; it.lat_g0 = q.g0;
+                        PTTS_HIP(hipMemcpyAsync(T.h_lat[it.parity] + static_cast<size_t>(q.slot) * R * L, b.latents.f() + static_cast<size_t>(q.slot) * R * L,
+                                                static_cast<size_t>(R) * L * 4, hipMemcpyDeviceToHost, dst));
+                    }
+                    dv.items.push_back(it);
+                }
+                dv.ev = get_event();
+                PTTS_HIP(hipEventRecord(dv.ev, dst));
+                PTTS_TRACEF("step %d: decoder call, %d frames from ring step %d, slots %d..%d, %d due", gs, n, due[a0].gstart, lo, hi, static_cast<int>(a1 - a0));
+                {
+                    std::lock_guard<std::mutex> lk(T.d_mu);
+                    T.deliveries.push_back(std::move(dv));
+                    T.due_pushed = a1;
+                    T.d_cv.notify_all();
+                }
+                a0 = a1;
+            }
+            T.due_reqs.clear(); T.due_pushed = 0;
+        }
+        ++gs;
+    }
+    // ---- the table is empty: everything still in flight lands, then the activation ends
+    {
+        std::unique_lock<std::mutex> lk(T.d_mu);
+        T.d_cv.wait(lk, [&] { return T.deliveries.empty() && T.in_flight == 0; });
+        if (T.d_err) { std::exception_ptr e = T.d_err; T.d_err = nullptr; std::rethrow_exception(e); }
+    }
+    PTTS_HIP(hipStreamSynchronize(st));
+    PTTS_HIP(hipStreamSynchronize(dst));
+    check_flow_ring(b.flow_ctl.as<unsigned>(), kSlots);
 }
 
 }  // namespace ptts

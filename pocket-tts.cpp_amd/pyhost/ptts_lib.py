@@ -47,11 +47,11 @@ DROP_IN_SYMBOLS = [
 ]
 EXT_SYMBOLS = [
     "pocket_tts_create_ex", "pocket_tts_dims", "pocket_tts_voice_from_embeddings", "pocket_tts_voice_frames",
-    "pocket_tts_voice_data", "pocket_tts_generate_batch", "pocket_tts_generate_ids", "pocket_tts_streaming_ids",
+    "pocket_tts_voice_data", "pocket_tts_generate_batch", "pocket_tts_generate_ids", "pocket_tts_generate_ids_queued", "pocket_tts_streaming_ids",
     "pocket_tts_stage_ids", "pocket_tts_run_staged", "pocket_tts_fetch_staged",
     "pocket_tts_tokenize", "ptts_text_conditioner", "ptts_state_new", "ptts_state_free", "ptts_state_reset",
     "ptts_lm_prefill", "ptts_lm_step", "ptts_flow_euler", "ptts_flow_euler_noalloc", "ptts_flow_euler_noalloc_capacity", "ptts_mimi_decode", "ptts_mimi_encode",
-    "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_q8_linear", "ptts_bf16_linear",
+    "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_scheduler_stats_ex", "ptts_q8_linear", "ptts_bf16_linear",
     "ptts_tokenizer_new", "ptts_tokenizer_free", "ptts_tokenizer_vocab", "ptts_tokenizer_encode",
     "ptts_audio_load_wav", "ptts_audio_save_wav", "ptts_audio_resample", "ptts_audio_normalize",
     "ptts_onnx_open", "ptts_onnx_close", "ptts_onnx_tensor_count", "ptts_onnx_tensor_info", "ptts_onnx_find",
@@ -94,6 +94,8 @@ def load() -> C.CDLL:
     L.pocket_tts_generate_ids.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(ci), C.POINTER(vp), C.POINTER(ci),
                                           C.POINTER(vp), C.POINTER(AudioResult), C.POINTER(vp), C.POINTER(vp),
                                           C.POINTER(ci), C.POINTER(ci)]
+    L.pocket_tts_generate_ids_queued.restype = ci
+    L.pocket_tts_generate_ids_queued.argtypes = L.pocket_tts_generate_ids.argtypes
     L.pocket_tts_stage_ids.restype = vp
     L.pocket_tts_stage_ids.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(ci), C.POINTER(vp), C.POINTER(ci), C.POINTER(vp)]
     L.pocket_tts_run_staged.restype = ci; L.pocket_tts_run_staged.argtypes = [vp, vp, C.POINTER(ci)]
@@ -115,6 +117,7 @@ def load() -> C.CDLL:
     L.ptts_phase_timing.restype = ci; L.ptts_phase_timing.argtypes = [vp, ci]
     L.ptts_phase_times.restype = ci; L.ptts_phase_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.ptts_scheduler_stats.restype = ci; L.ptts_scheduler_stats.argtypes = [vp, C.POINTER(C.c_long)]
+    L.ptts_scheduler_stats_ex.restype = ci; L.ptts_scheduler_stats_ex.argtypes = [vp, C.POINTER(C.c_long)]
     L.ptts_q8_linear.restype = ci; L.ptts_q8_linear.argtypes = [vp, f32p, ci, ci, f32p, ci, f32p]
     L.ptts_bf16_linear.restype = ci
     L.ptts_bf16_linear.argtypes = [vp, f32p, ci, ci, f32p, ci, vp, vp, vp, ci, ci, f32p]
@@ -323,7 +326,8 @@ class Engine:
     # ---- whole path ----
     def generate_ids(self, ids_list: Sequence[np.ndarray], voices: Sequence[np.ndarray],
                      noise: Optional[Sequence[Optional[np.ndarray]]] = None, want_latents: bool = True,
-                     want_audio: bool = True) -> List[dict]:
+                     want_audio: bool = True, queued: bool = False) -> List[dict]:
+        """queued: through the slot table (continuous batching, any n) instead of one lock-step batch."""
         n = len(ids_list)
         ids_keep = [np.ascontiguousarray(a, np.int64) for a in ids_list]
         v_keep = [np.ascontiguousarray(v, np.float32) for v in voices]
@@ -344,7 +348,8 @@ class Engine:
         eos_p = (vp * n)(*[a.ctypes.data for a in eos]) if want_latents else None
         frames = (C.c_int * n)()
         neos = (C.c_int * n)()
-        _check(self.L.pocket_tts_generate_ids(self.h, n, ids_p, nid, v_p, vf, no_p, res, lat_p, eos_p, frames, neos), "generate_ids")
+        fn = self.L.pocket_tts_generate_ids_queued if queued else self.L.pocket_tts_generate_ids
+        _check(fn(self.h, n, ids_p, nid, v_p, vf, no_p, res, lat_p, eos_p, frames, neos), "generate_ids")
         out = []
         for i in range(n):
             d = dict(frames=int(frames[i]))
@@ -447,9 +452,10 @@ class Engine:
         return out
 
     def scheduler_stats(self):
-        st = (C.c_long * 3)()
-        _check(self.L.ptts_scheduler_stats(self.h, st), "scheduler_stats")
-        return dict(batches=st[0], utterances=st[1], largest=st[2])
+        st = (C.c_long * 8)()
+        _check(self.L.ptts_scheduler_stats_ex(self.h, st), "scheduler_stats")
+        return dict(batches=st[0], utterances=st[1], largest=st[2], frame_steps=st[3], slot_steps=st[4], frames=st[5],
+                    decode_calls=st[6], admissions=st[7])
 
     def weight_bytes(self):
         b = (C.c_ulonglong * 4)()

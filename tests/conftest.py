@@ -28,6 +28,7 @@ def packs(tmp_path_factory):
 
     make("tiny", pp.Spec.tiny(), 7, -20.0, 0.2)
     make("tiny_eos", pp.Spec.tiny(), 7, -4.6, 0.2)   # EOS logit hovers around the -4.0 threshold
+    make("tiny_spread", pp.Spec.tiny(), 7, -6.6, 0.2)   # first crossing of the threshold spread over ~3..150+ steps
     make("small", pp.Spec.small(), 11, -20.0, 0.1)
     return out
 
