@@ -2,9 +2,11 @@
 // streaming decode schedules, the voice encoder and the graph-level entry points.
 // The loop bodies restate /root/reference/src/pocket_tts.cpp:548-657 (offline) and :686-979 (streaming).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 #include "engine.h"
 
@@ -280,12 +282,14 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
         times_.lm_ms += lm; times_.lm_calls++;
         times_.flow_ms += fl; times_.flow_calls++;
         FlowHeadArgs fa;
-        fa.C = spec().flow_dim; fa.B = b.B; fa.steps = opt_.lsd_steps; fa.blocks = spec().flow_blocks;
+        fa.C = spec().flow_dim; fa.L = spec().latent; fa.B = b.Bw; fa.steps = opt_.lsd_steps; fa.blocks = spec().flow_blocks;
         fa.wtype = model_->flow_wtype; fa.block_wtype = model_->flow_block_wtype;
+        fa.ring_ctl = b.flow_ctl.as<unsigned>(); fa.ring_wg_budget = 224 / std::max(lanes_, 1);
         times_.head_ms += hd; times_.head_calls += flow_head_launch_count(fa);
     };
 
     size_t n_finished = 0;
+    FlagWait flag_wait;
     while (n_finished < runs.size()) {
         for (auto& r : runs) {
             if (r.finished || r.launched) continue;
@@ -295,10 +299,11 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
             else frame_body(b, r.step & 1);
             r.launched = true;
         }
+        if (runs.size() == 1 && runs[0].launched && !runs[0].finished) wait_flag(runs[0].b->h_flag, runs[0].step + 1, runs[0].b->st, flag_wait);
         for (auto& r : runs) {
             if (r.finished || !r.launched) continue;
             Batch& b = *r.b;
-            if (__atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < r.step + 1) continue;   // EOS logits of this step not here yet
+            if (__atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < r.step + 1) { __builtin_ia32_pause(); continue; }   // EOS logits of this step not here yet
             const int B = b.B, step = r.step;
             r.executed = step + 1;
             if (timing_ && step > 0) { collect_timing(b, (step - 1) & 1); r.timed = step; }   // frame step-1 has fully retired
@@ -421,6 +426,7 @@ int Engine::generate_streaming_inline(const Utterance& utt, int chunk_frames, co
     b.x0_src = b.x0.f(); b.x0_stride = L; b.x0_step_stride = 0;   // start points arrive frame by frame
     if (!any_noise) PTTS_HIP(hipMemsetAsync(b.x0.p, 0, static_cast<size_t>(L) * 4, st));
     const bool graph = use_graph_ && !timing_;
+    FlagWait flag_wait;
     hipGraphExec_t* exec = nullptr;
     if (graph) {
         const std::vector<int> keep = b.lm_pos_host;
@@ -455,10 +461,7 @@ int Engine::generate_streaming_inline(const Utterance& utt, int chunk_frames, co
         }
         if (graph) PTTS_HIP(hipGraphLaunch(exec[step & 1], st));                     // :753, :777-784
         else frame_body(b, step & 1);
-        for (unsigned spins = 1; __atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < step + 1; ++spins) {
-            if ((spins & 0xffff) == 0 && hipStreamQuery(st) == hipSuccess && __atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < step + 1)
-                throw std::runtime_error("frame finished without publishing its EOS logit");
-        }
+        wait_flag(b.h_flag, step + 1, st, flag_wait);
         const float e = b.h_eos_all[step];
         if (capture) capture->eos.push_back(e);
         if (e > kEosThreshold && eos_step < 0) eos_step = step;                            // :758
@@ -736,6 +739,22 @@ void Engine::op_mimi_decode(Batch* b, const float* latents, int n, float* audio)
     PTTS_HIP(hipMemcpy2DAsync(audio, static_cast<size_t>(n) * fs * 4, b->audio.p, static_cast<size_t>(kDecChunk) * fs * 4,
                               static_cast<size_t>(n) * fs * 4, b->B, hipMemcpyDeviceToHost, stream_));
     PTTS_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::wait_flag(const int* flag, int target, hipStream_t st, FlagWait& w) {
+    static const int sleep_pct = [] { const char* e = std::getenv("POCKET_TTS_WAIT_SLEEP_PCT"); return e ? std::max(0, std::min(90, std::atoi(e))) : 0; }();
+    const auto t0 = std::chrono::steady_clock::now();
+    if (sleep_pct > 0 && w.avg_us > 150.0) std::this_thread::sleep_for(std::chrono::microseconds(static_cast<long>(w.avg_us * sleep_pct / 100.0)));
+    for (unsigned spins = 1; __atomic_load_n(flag, __ATOMIC_ACQUIRE) < target; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0x3fff) == 0) {
+            const bool idle = hipStreamQuery(st) == hipSuccess;
+            if (!idle) (void)hipGetLastError();
+            if (idle && __atomic_load_n(flag, __ATOMIC_ACQUIRE) < target) throw std::runtime_error("frame finished without publishing its EOS logits");
+        }
+    }
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    w.avg_us = w.avg_us > 0 ? 0.9 * w.avg_us + 0.1 * us : us;
 }
 
 }  // namespace ptts

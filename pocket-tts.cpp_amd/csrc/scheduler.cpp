@@ -471,6 +471,7 @@ void Engine::run_table() {
 
     int gather_us = 100;
     if (const char* e = std::getenv("POCKET_TTS_GATHER_US")) gather_us = std::max(0, std::atoi(e));
+    FlagWait flag_wait;
     int gs = 0;   // the table's clock: frame steps launched so far
     for (;;) {
         // ---- admission
@@ -596,16 +597,7 @@ void Engine::run_table() {
         }
         gpu.unlock();
         // ---- the EOS logits of this step (the flow head of the step is still running when they arrive)
-        for (unsigned spins = 1; __atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < gs + 1; ++spins) {
-            if ((spins & 0x3ff) == 0) {
-                gpu.lock();
-                const bool idle = hipStreamQuery(st) == hipSuccess;
-                if (!idle) (void)hipGetLastError();
-                gpu.unlock();
-                if (idle && __atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < gs + 1) throw std::runtime_error("frame finished without publishing its EOS logits");
-                std::this_thread::yield();
-            }
-        }
+        wait_flag(b.h_flag, gs + 1, st, flag_wait);
         gpu.lock();
         const float* e_now = b.h_eos_all + static_cast<size_t>(gs % b.eos_ring) * b.B;
         struct Due { Request* req; int slot, n, f0, gstart; bool last_sub, is_final, closes; int g0, generation; };

@@ -2,8 +2,8 @@
 
 Every utterance is independent (the reference serves one at a time, src/pocket_tts.cpp:532-664), so the
 only cross-rank traffic is the control plane: a barrier around the timed region and two scalar reductions
-(MAX of the wall time, SUM of the frames produced).  The helpers take the process group's backend as it is
-("nccl" = RCCL on the GPU box, "gloo" in the CPU tests).
+(MAX of the wall time, SUM of the frames produced).  They run over gloo on host tensors, on the GPU box as in the
+CPU tests: the data path has no collective, so RCCL is not loaded at all.
 """
 from __future__ import annotations
 
@@ -39,12 +39,10 @@ def batches(jobs: Sequence[int], costs: Sequence[float], max_batch: int) -> List
 
 
 def barrier(dist, device=None) -> None:
+    """Every engine call returns with its stream drained, so a host barrier brackets the timed region exactly."""
     if dist is None:
         return
     dist.barrier()
-    if device is not None and device.type == "cuda":
-        import torch
-        torch.cuda.synchronize(device)
 
 
 def reduce_job(dt_local: float, units_local: float, dist, device=None) -> Tuple[float, float]:
@@ -52,8 +50,8 @@ def reduce_job(dt_local: float, units_local: float, dist, device=None) -> Tuple[
     if dist is None:
         return float(dt_local), float(units_local)
     import torch
-    t = torch.tensor([dt_local], dtype=torch.float64, device=device)
-    u = torch.tensor([units_local], dtype=torch.float64, device=device)
+    t = torch.tensor([dt_local], dtype=torch.float64)
+    u = torch.tensor([units_local], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t.item()), float(u.item())
