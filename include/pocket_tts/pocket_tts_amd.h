@@ -127,6 +127,10 @@ POCKET_TTS_API int ptts_mimi_decode(PocketTTSHandle handle, void* state, const f
 /* mimi_encoder: audio[samples] at 24 kHz -> out[frames][d_model]; returns frames (rows written <= cap_frames)
  * or -1                                                             (src/pocket_tts.cpp:261-291). */
 POCKET_TTS_API int ptts_mimi_encode(PocketTTSHandle handle, const float* audio, int samples, float* out, int cap_frames);
+/* The same over n_clips clips of `samples` samples each, stacked through the encoder together (the reference encodes one
+ * clip per call, src/pocket_tts.cpp:241-297): outs[i] receives clip i's rows; returns the rows per clip. */
+POCKET_TTS_API int ptts_mimi_encode_batch(PocketTTSHandle handle, const float* const* clips, int n_clips, int samples, float* const* outs,
+                                          int cap_frames);
 
 /* ---- host-side pre/post steps, usable without a GPU ---------------------------------------------- */
 

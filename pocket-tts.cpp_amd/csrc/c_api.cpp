@@ -444,6 +444,25 @@ POCKET_TTS_API int ptts_mimi_encode(PocketTTSHandle handle, const float* audio, 
     });
 }
 
+POCKET_TTS_API int ptts_mimi_encode_batch(PocketTTSHandle handle, const float* const* clips, int n_clips, int samples, float* const* outs,
+                                          int cap_frames) {
+    if (!handle || !clips || !outs || n_clips <= 0 || samples <= 0) { set_error("Invalid parameters"); return -1; }
+    return guarded("mimi_encode_batch: ", [&] {
+        auto& e = tts_of(handle)->engine();
+        std::vector<const float*> ptrs(clips, clips + n_clips);
+        std::vector<int> lens(static_cast<size_t>(n_clips), samples);
+        std::vector<std::vector<float>> emb;
+        e.encode_voice_batch(ptrs, lens, emb);
+        const int D = e.spec().d_model;
+        int frames = 0;
+        for (int i = 0; i < n_clips; ++i) {
+            frames = static_cast<int>(emb[i].size()) / D;
+            std::memcpy(outs[i], emb[i].data(), static_cast<size_t>(std::min(frames, cap_frames)) * D * 4);
+        }
+        return frames;
+    });
+}
+
 POCKET_TTS_API void* ptts_tokenizer_new(const char* model_path) {
     if (!model_path) { set_error("Invalid parameters"); return nullptr; }
     try {

@@ -632,6 +632,7 @@ Engine::~Engine() {
     batch_pool_.clear();
     drop_table();
     PTTS_TRACE("dtor: table dropped");
+    if (enc_pin_) (void)hipHostFree(enc_pin_);
     for (auto& pe : pending_events_) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     if (ev_[0]) (void)hipEventDestroy(ev_[0]);
     if (ev_[1]) (void)hipEventDestroy(ev_[1]);

@@ -190,6 +190,7 @@ public:
                                   UtteranceResult* capture);
     // Voice encoder: audio f32[S] at the model rate -> [frames][d_model]  (src/pocket_tts.cpp:261-291)
     std::vector<float> encode_voice(const float* audio, int S);
+    void encode_clips(const float* const* clips, int B, int S, std::vector<std::vector<float>>& out);
     void encode_voice_batch(const std::vector<const float*>& clips, const std::vector<int>& lens,
                             std::vector<std::vector<float>>& out);
 
@@ -274,6 +275,8 @@ private:
     void init_static_scratch();
     DevBuf flow_te_;  // [lsd_steps][C] averaged time embeddings of the fixed (s_j, t_j) grid
     DevBuf enc_arena_;   // every buffer of a voice-encoder pass, kept between calls
+    float* enc_pin_ = nullptr;   // pinned staging of a pass's clips
+    size_t enc_pin_bytes_ = 0;
     std::map<std::pair<int, int>, std::unique_ptr<Batch>> batch_pool_;   // (rows, lane)
     std::vector<hipStream_t> lane_streams_;     // lane 0 = stream_
     std::vector<hipEvent_t> lane_events_;

@@ -494,37 +494,55 @@ int Engine::generate_streaming_inline(const Utterance& utt, int chunk_frames, co
 // ------------------------------------------------------------------------------------------ voice encoder
 
 std::vector<float> Engine::encode_voice(const float* audio, int S) {
+    std::vector<std::vector<float>> out;
+    encode_clips(&audio, 1, S, out);
+    return std::move(out[0]);
+}
+
+// B clips of S samples each -> B embeddings [ceil(frames)][d_model] (src/pocket_tts.cpp:241-297 for one clip).
+// The clips are stacked along the row dimension of every product: the SEANet stages and the transformer's linear layers
+// see B times the rows (at one clip the stages behind the second down-sampling run a few hundred workgroups or fewer),
+// attention runs per clip.
+void Engine::encode_clips(const float* const* clips, int B, int S, std::vector<std::vector<float>>& out) {
     std::lock_guard<std::mutex> guard(mu_);
     PTTS_HIP(hipSetDevice(opt_.device));
     const Spec& s = spec();
-    if (S <= 0) throw std::runtime_error("voice clip is empty");
+    if (S <= 0 || B <= 0) throw std::runtime_error("voice clip is empty");
     const int M = s.mimi_dim, U = s.upsample, D = s.d_model, rk = s.res_kernel, lk = s.last_kernel;
     const int ds_splits = 8;
-    // Every buffer of the pass is a slice of one arena that is kept between calls (a clip is encoded without a
+    const size_t Bz = static_cast<size_t>(B);
+    // Every buffer of the pass is a slice of one arena that is kept between calls (clips are encoded without a
     // device allocation or a stream synchronisation before the result is copied out).  First the sizes, in the
     // order the slices are taken below.
     auto rounded = [](size_t floats) { return (floats * 4 + 255) & ~static_cast<size_t>(255); };
-    size_t need = rounded(S);
+    size_t need = rounded(Bz * S);
     {
         int c = s.n_filters, T = S;
-        need += rounded(static_cast<size_t>(T) * c) + rounded(static_cast<size_t>(rk - 1 + T) * c);
+        need += rounded(Bz * T * c) + rounded(Bz * (rk - 1 + T) * c);
         for (int i = 0; i < 3; ++i) {
             const int r = s.ratios[2 - i], To = (T + r - 1) / r, Tpad = To * r, pn = i < 2 ? rk - 1 : lk - 1;
-            need += rounded(static_cast<size_t>(T) * (c / 2)) + rounded(static_cast<size_t>(r + Tpad) * c) +
-                    rounded(static_cast<size_t>(To) * 2 * c) + rounded(static_cast<size_t>(pn + To) * 2 * c);
+            need += rounded(Bz * T * (c / 2)) + rounded(Bz * (r + Tpad) * c) +
+                    rounded(Bz * To * 2 * c) + rounded(Bz * (pn + To) * 2 * c);
             T = To; c *= 2;
         }
         if (T > 16000) throw std::runtime_error("voice clip too long for the encoder attention buffer");
         if (T > model_->mimi_tab_len) throw std::runtime_error("voice clip exceeds the rotary table");
         const int Nv = (T + U - 1) / U, Tpad = Nv * U;
-        const size_t TM = static_cast<size_t>(T) * M;
-        need += rounded(TM) + 2 * rounded(static_cast<size_t>(s.mimi_layers) * TM) + rounded(1) + 3 * rounded(TM) + rounded(3 * TM) +
-                rounded(static_cast<size_t>(T) * s.mimi_ffn) + rounded(static_cast<size_t>(U + Tpad) * M) +
-                rounded(static_cast<size_t>(Nv) * M) + rounded(static_cast<size_t>(Nv) * D) + rounded(static_cast<size_t>(ds_splits) * Nv * M);
+        const size_t TM = Bz * T * M;
+        need += rounded(TM) + 2 * rounded(static_cast<size_t>(s.mimi_layers) * TM) + rounded(Bz) + 3 * rounded(TM) + rounded(3 * TM) +
+                rounded(Bz * T * s.mimi_ffn) + rounded(Bz * (U + Tpad) * M) +
+                2 * rounded(Bz * (1 + Nv) * M) + rounded(Bz * (1 + Nv) * D) + rounded(static_cast<size_t>(ds_splits) * Bz * (1 + Nv) * M);
     }
     if (enc_arena_.bytes < need) {
         PTTS_HIP(hipStreamSynchronize(stream_));
         enc_arena_.alloc(need);
+    }
+    if (enc_pin_bytes_ < Bz * S * 4) {
+        PTTS_HIP(hipStreamSynchronize(stream_));
+        if (enc_pin_) PTTS_HIP(hipHostFree(enc_pin_));
+        enc_pin_ = nullptr; enc_pin_bytes_ = 0;
+        PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&enc_pin_), Bz * S * 4));
+        enc_pin_bytes_ = Bz * S * 4;
     }
     size_t top = 0;
     auto take = [&](size_t floats, bool zero = false) -> float* {
@@ -535,95 +553,128 @@ std::vector<float> Engine::encode_voice(const float* audio, int S) {
         if (zero) PTTS_HIP(hipMemsetAsync(p, 0, floats * 4, stream_));
         return p;
     };
-    float* dau = take(S);
-    PTTS_HIP(hipMemcpyAsync(dau, audio, static_cast<size_t>(S) * 4, hipMemcpyHostToDevice, stream_));
+    // rows [first, first + count) of every clip's segment (seg rows of width floats each) set to zero
+    auto zero_rows = [&](float* base, size_t seg, size_t first, size_t count, size_t width) {
+        if (count == 0) return;
+        PTTS_HIP(hipMemset2DAsync(base + first * width, seg * width * 4, 0, count * width * 4, Bz, stream_));
+    };
+    float* dau = take(Bz * S);
+    for (int b = 0; b < B; ++b) std::memcpy(enc_pin_ + static_cast<size_t>(b) * S, clips[b], static_cast<size_t>(S) * 4);
+    PTTS_HIP(hipMemcpyAsync(dau, enc_pin_, Bz * S * 4, hipMemcpyHostToDevice, stream_));
     int c = s.n_filters, T = S;
-    float* xraw = take(static_cast<size_t>(T) * c);
-    float* xe = take(static_cast<size_t>(rk - 1 + T) * c);
-    PTTS_HIP(hipMemsetAsync(xe, 0, static_cast<size_t>(rk - 1) * c * 4, stream_));   // left padding of the causal convolution
-    launch_conv_from_mono(dau, 0, nullptr, T, s.kernel, c, hd_.enc_conv0_w, hd_.enc_conv0_b, xraw, 0,
-                          xe + static_cast<size_t>(rk - 1) * c, 0, 1, stream_);
+    float* xraw = take(Bz * T * c);
+    float* xe = take(Bz * (rk - 1 + T) * c);
+    size_t xe_seg = static_cast<size_t>(rk - 1 + T);            // rows per clip in xe; its first rows are the causal left padding
+    int xe_pad = rk - 1;
+    zero_rows(xe, xe_seg, 0, xe_pad, c);
+    launch_conv_from_mono(dau, S, nullptr, T, s.kernel, c, hd_.enc_conv0_w, hd_.enc_conv0_b, xraw, static_cast<long long>(T) * c,
+                          xe + static_cast<size_t>(xe_pad) * c, static_cast<long long>(xe_seg) * c, B, stream_);
     for (int i = 0; i < 3; ++i) {
         const int r = s.ratios[2 - i], To = (T + r - 1) / r, Tpad = To * r;
-        float* h1 = take(static_cast<size_t>(T) * (c / 2));
+        float* h1 = take(Bz * T * (c / 2));
         GemmArgs c1;
-        c1.A = xe; c1.lda = c; c1.W = hd_.enc_c1[i].p; c1.wtype = hd_.enc_c1[i].wtype; c1.bias = hd_.enc_c1_b[i];
-        c1.M = T; c1.N = c / 2; c1.K = rk * c; c1.C = h1; c1.ldc = c / 2; c1.c_act = ACT_ELU;
+        c1.A = xe; c1.lda = c; c1.a_bs = static_cast<long long>(xe_seg) * c; c1.rpb = T;
+        c1.W = hd_.enc_c1[i].p; c1.wtype = hd_.enc_c1[i].wtype; c1.bias = hd_.enc_c1_b[i];
+        c1.M = B * T; c1.N = c / 2; c1.K = rk * c; c1.C = h1; c1.ldc = c / 2; c1.c_bs = static_cast<long long>(T) * (c / 2); c1.c_act = ACT_ELU;
         launch_gemm(c1, stream_);
-        // rows [r, r + T) are written by the product below; the padding before and after them stays zero
-        float* ye = take(static_cast<size_t>(r + Tpad) * c);
-        PTTS_HIP(hipMemsetAsync(ye, 0, static_cast<size_t>(r) * c * 4, stream_));
-        if (Tpad > T) PTTS_HIP(hipMemsetAsync(ye + static_cast<size_t>(r + T) * c, 0, static_cast<size_t>(Tpad - T) * c * 4, stream_));
+        // rows [r, r + T) of a clip's segment are written by the product below; the padding before and after them stays zero
+        const size_t ye_seg = static_cast<size_t>(r + Tpad);
+        float* ye = take(Bz * ye_seg * c);
+        zero_rows(ye, ye_seg, 0, r, c);
+        zero_rows(ye, ye_seg, static_cast<size_t>(r + T), static_cast<size_t>(Tpad - T), c);
         GemmArgs c2;
-        c2.A = h1; c2.lda = c / 2; c2.W = hd_.enc_c2[i].p; c2.wtype = hd_.enc_c2[i].wtype; c2.bias = hd_.enc_c2_b[i];
-        c2.M = T; c2.N = c; c2.K = c / 2; c2.R = xraw; c2.ldr = c; c2.C = ye + static_cast<size_t>(r) * c; c2.ldc = c; c2.c_act = ACT_ELU;
+        c2.A = h1; c2.lda = c / 2; c2.a_bs = static_cast<long long>(T) * (c / 2); c2.rpb = T;
+        c2.W = hd_.enc_c2[i].p; c2.wtype = hd_.enc_c2[i].wtype; c2.bias = hd_.enc_c2_b[i];
+        c2.M = B * T; c2.N = c; c2.K = c / 2; c2.R = xraw; c2.ldr = c; c2.r_bs = static_cast<long long>(T) * c;
+        c2.C = ye + static_cast<size_t>(r) * c; c2.ldc = c; c2.c_bs = static_cast<long long>(ye_seg) * c; c2.c_act = ACT_ELU;
         launch_gemm(c2, stream_);
         const int pn = i < 2 ? rk - 1 : lk - 1;
-        float* xraw2 = take(static_cast<size_t>(To) * 2 * c);
-        float* xe2 = take(static_cast<size_t>(pn + To) * 2 * c);
-        PTTS_HIP(hipMemsetAsync(xe2, 0, static_cast<size_t>(pn) * 2 * c * 4, stream_));
+        float* xraw2 = take(Bz * To * 2 * c);
+        const size_t xe2_seg = static_cast<size_t>(pn + To);
+        float* xe2 = take(Bz * xe2_seg * 2 * c);
+        zero_rows(xe2, xe2_seg, 0, pn, 2 * c);
         GemmArgs dn;
-        dn.A = ye; dn.lda = r * c; dn.W = hd_.enc_down[i].p; dn.wtype = hd_.enc_down[i].wtype; dn.bias = hd_.enc_down_b[i];
-        dn.M = To; dn.N = 2 * c; dn.K = 2 * r * c; dn.C = xraw2; dn.ldc = 2 * c;
-        dn.C2 = xe2 + static_cast<size_t>(pn) * 2 * c; dn.ldc2 = 2 * c; dn.c2_act = ACT_ELU;
+        dn.A = ye; dn.lda = r * c; dn.a_bs = static_cast<long long>(ye_seg) * c; dn.rpb = To;
+        dn.W = hd_.enc_down[i].p; dn.wtype = hd_.enc_down[i].wtype; dn.bias = hd_.enc_down_b[i];
+        dn.M = B * To; dn.N = 2 * c; dn.K = 2 * r * c; dn.C = xraw2; dn.ldc = 2 * c; dn.c_bs = static_cast<long long>(To) * 2 * c;
+        dn.C2 = xe2 + static_cast<size_t>(pn) * 2 * c; dn.ldc2 = 2 * c; dn.c2_bs = static_cast<long long>(xe2_seg) * 2 * c; dn.c2_act = ACT_ELU;
         launch_gemm(dn, stream_);
         xraw = xraw2;
-        xe = xe2;
+        xe = xe2; xe_seg = xe2_seg; xe_pad = pn;
         T = To; c *= 2;
     }
-    float* y = take(static_cast<size_t>(T) * M);
+    float* y = take(Bz * T * M);
     GemmArgs fin;
-    fin.A = xe; fin.lda = c; fin.W = hd_.enc_final.p; fin.wtype = hd_.enc_final.wtype; fin.bias = hd_.enc_final_b;
-    fin.M = T; fin.N = M; fin.K = lk * c; fin.C = y; fin.ldc = M;
+    fin.A = xe; fin.lda = c; fin.a_bs = static_cast<long long>(xe_seg) * c; fin.rpb = T;
+    fin.W = hd_.enc_final.p; fin.wtype = hd_.enc_final.wtype; fin.bias = hd_.enc_final_b;
+    fin.M = B * T; fin.N = M; fin.K = lk * c; fin.C = y; fin.ldc = M; fin.c_bs = static_cast<long long>(T) * M;
     launch_gemm(fin, stream_);
-    // transformer over the whole clip from position 0
+    // transformer over every clip from position 0 (attention per clip)
     const int Nv = (T + U - 1) / U, Tpad = Nv * U;
-    const size_t TM = static_cast<size_t>(T) * M;
+    const size_t TM = Bz * T * M;
     float* kc = take(static_cast<size_t>(s.mimi_layers) * TM);
     float* vc = take(static_cast<size_t>(s.mimi_layers) * TM);
-    int* pos = reinterpret_cast<int*>(take(1, true));
+    int* pos = reinterpret_cast<int*>(take(Bz, true));
     float* sh = take(TM); float* sq = take(TM); float* satt = take(TM);
     float* sqkv = take(3 * TM);
-    float* sff = take(static_cast<size_t>(T) * s.mimi_ffn);
+    float* sff = take(Bz * T * s.mimi_ffn);
     TfScratch sc{sh, sqkv, sq, satt, sff};
-    float* yd = take(static_cast<size_t>(U + Tpad) * M);
-    PTTS_HIP(hipMemsetAsync(yd, 0, static_cast<size_t>(U) * M * 4, stream_));
-    if (Tpad > T) PTTS_HIP(hipMemsetAsync(yd + static_cast<size_t>(U + T) * M, 0, static_cast<size_t>(Tpad - T) * M * 4, stream_));
-    transformer(hd_.enc, kc, vc, 0, static_cast<long long>(T) * M, T, pos, 0, 1, T, y, M, s.mimi_heads, s.mimi_ffn,
+    const size_t yd_seg = static_cast<size_t>(U + Tpad);
+    float* yd = take(Bz * yd_seg * M);
+    zero_rows(yd, yd_seg, 0, U, M);
+    zero_rows(yd, yd_seg, static_cast<size_t>(U + T), static_cast<size_t>(Tpad - T), M);
+    transformer(hd_.enc, kc, vc, 0, static_cast<long long>(TM), T, pos, 0, B, T, y, M, s.mimi_heads, s.mimi_ffn,
                 s.mimi_eps, s.mimi_context, model_->mimi_cos, model_->mimi_sin, model_->mimi_tab_len, sc,
-                yd + static_cast<size_t>(U) * M, 0, M, stream_);
-    float* d2 = take(static_cast<size_t>(Nv) * M);
-    float* o = take(static_cast<size_t>(Nv) * D);
-    float* slabs = take(static_cast<size_t>(ds_splits) * Nv * M);
+                yd + static_cast<size_t>(U) * M, static_cast<long long>(yd_seg) * M, M, stream_);
+    // Down-sampling by U with a kernel of 2 U: output row j of a clip reads 2 U rows from row j U of its segment, i.e. two
+    // consecutive "rows" of U M floats.  A clip's segment is 1 + Nv such rows, so over the stacked segments row b (1 + Nv) + j
+    // is output j of clip b for j < Nv, and row j = Nv (which straddles two clips) is computed and never read.
+    const int seg = 1 + Nv, rows = B * seg - 1;
+    float* d2 = take(Bz * seg * M);
+    float* o = take(Bz * seg * D);
+    float* slabs = take(static_cast<size_t>(ds_splits) * Bz * seg * M);
     const int dsK = 2 * U * M;
-    if (model_->enc_ds_packed && Nv <= 128 && M <= 1024 && dsK % (ds_splits * 16) == 0 && !std::getenv("POCKET_TTS_NO_SKINNY_ENCODER")) {
-        // Nv rows against a K of 2 * U * M: eight workgroups as a tiled GEMM; as K-slices on the skinny kernel the
+    if (model_->enc_ds_packed && M <= 1024 && dsK % (ds_splits * 16) == 0 && !std::getenv("POCKET_TTS_NO_SKINNY_ENCODER")) {
+        // few rows against a K of 2 * U * M: eight workgroups as a tiled GEMM; as K-slices on the skinny kernel the
         // product fills the chip, and the add & norm kernel sums the slices
         SkinnyArgs k;
-        k.A = yd; k.lda = U * M; k.Wp = model_->enc_ds_packed; k.wtype = W_F32; k.M = Nv; k.N = M; k.K = dsK; k.splits = ds_splits; k.P = slabs;
+        k.A = yd; k.lda = U * M; k.Wp = model_->enc_ds_packed; k.wtype = W_F32; k.M = rows; k.N = M; k.K = dsK; k.splits = ds_splits; k.P = slabs;
         launch_skinny_gemm(k, stream_);
-        PTTS_HIP(hipMemsetAsync(d2, 0, static_cast<size_t>(Nv) * M * 4, stream_));
+        PTTS_HIP(hipMemsetAsync(d2, 0, static_cast<size_t>(rows) * M * 4, stream_));
         AddNormArgs an;
-        an.X = d2; an.ldx = M; an.M = Nv; an.D = M; an.P = slabs; an.splits = ds_splits;
+        an.X = d2; an.ldx = M; an.M = rows; an.D = M; an.P = slabs; an.splits = ds_splits;
         launch_add_norm(an, stream_);
     } else {
         GemmArgs ds;
-        ds.A = yd; ds.lda = U * M; ds.W = hd_.enc_ds.p; ds.wtype = hd_.enc_ds.wtype; ds.M = Nv; ds.N = M; ds.K = dsK; ds.C = d2; ds.ldc = M;
+        ds.A = yd; ds.lda = U * M; ds.W = hd_.enc_ds.p; ds.wtype = hd_.enc_ds.wtype; ds.M = rows; ds.N = M; ds.K = dsK; ds.C = d2; ds.ldc = M;
         launch_gemm(ds, stream_);
     }
     GemmArgs sp;
-    sp.A = d2; sp.lda = M; sp.W = hd_.enc_spk.p; sp.wtype = hd_.enc_spk.wtype; sp.M = Nv; sp.N = D; sp.K = M; sp.C = o; sp.ldc = D;
+    sp.A = d2; sp.lda = M; sp.W = hd_.enc_spk.p; sp.wtype = hd_.enc_spk.wtype; sp.M = rows; sp.N = D; sp.K = M; sp.C = o; sp.ldc = D;
     launch_gemm(sp, stream_);
     check_launches("the voice encoder");
-    std::vector<float> out(static_cast<size_t>(Nv) * D);
-    PTTS_HIP(hipMemcpyAsync(out.data(), o, out.size() * 4, hipMemcpyDeviceToHost, stream_));
+    out.assign(Bz, std::vector<float>(static_cast<size_t>(Nv) * D));
+    for (int b = 0; b < B; ++b)
+        PTTS_HIP(hipMemcpyAsync(out[b].data(), o + static_cast<size_t>(b) * seg * D, out[b].size() * 4, hipMemcpyDeviceToHost, stream_));
     PTTS_HIP(hipStreamSynchronize(stream_));
-    return out;
 }
 
+// Clips of equal length go through the encoder together, up to POCKET_TTS_ENCODE_BATCH (default 8) at a time.
 void Engine::encode_voice_batch(const std::vector<const float*>& clips, const std::vector<int>& lens, std::vector<std::vector<float>>& out) {
-    out.clear();
-    for (size_t i = 0; i < clips.size(); ++i) out.push_back(encode_voice(clips[i], lens[i]));
+    static const int max_b = [] { const char* e = std::getenv("POCKET_TTS_ENCODE_BATCH"); return e ? std::max(1, std::min(64, std::atoi(e))) : 8; }();
+    out.assign(clips.size(), std::vector<float>());
+    std::vector<char> done(clips.size(), 0);
+    for (size_t i = 0; i < clips.size(); ++i) {
+        if (done[i]) continue;
+        std::vector<size_t> group{i};
+        for (size_t j = i + 1; j < clips.size() && group.size() < static_cast<size_t>(max_b); ++j)
+            if (!done[j] && lens[j] == lens[i]) group.push_back(j);
+        std::vector<const float*> ptrs;
+        for (size_t g : group) { ptrs.push_back(clips[g]); done[g] = 1; }
+        std::vector<std::vector<float>> part;
+        encode_clips(ptrs.data(), static_cast<int>(ptrs.size()), lens[i], part);
+        for (size_t k = 0; k < group.size(); ++k) out[group[k]] = std::move(part[k]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ graph-level entry points

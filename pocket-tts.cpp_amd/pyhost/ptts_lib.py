@@ -50,7 +50,7 @@ EXT_SYMBOLS = [
     "pocket_tts_voice_data", "pocket_tts_generate_batch", "pocket_tts_generate_ids", "pocket_tts_generate_ids_queued", "pocket_tts_streaming_ids",
     "pocket_tts_stage_ids", "pocket_tts_run_staged", "pocket_tts_fetch_staged",
     "pocket_tts_tokenize", "ptts_text_conditioner", "ptts_state_new", "ptts_state_free", "ptts_state_reset",
-    "ptts_lm_prefill", "ptts_lm_step", "ptts_flow_euler", "ptts_flow_euler_noalloc", "ptts_flow_euler_noalloc_capacity", "ptts_mimi_decode", "ptts_mimi_encode",
+    "ptts_lm_prefill", "ptts_lm_step", "ptts_flow_euler", "ptts_flow_euler_noalloc", "ptts_flow_euler_noalloc_capacity", "ptts_mimi_decode", "ptts_mimi_encode", "ptts_mimi_encode_batch",
     "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_scheduler_stats_ex", "ptts_q8_linear", "ptts_bf16_linear",
     "ptts_tokenizer_new", "ptts_tokenizer_free", "ptts_tokenizer_vocab", "ptts_tokenizer_encode",
     "ptts_audio_load_wav", "ptts_audio_save_wav", "ptts_audio_resample", "ptts_audio_normalize",
@@ -114,6 +114,7 @@ def load() -> C.CDLL:
     L.ptts_flow_euler_noalloc_capacity.restype = C.c_ulonglong; L.ptts_flow_euler_noalloc_capacity.argtypes = []
     L.ptts_mimi_decode.restype = ci; L.ptts_mimi_decode.argtypes = [vp, vp, f32p, ci, f32p]
     L.ptts_mimi_encode.restype = ci; L.ptts_mimi_encode.argtypes = [vp, f32p, ci, f32p, ci]
+    L.ptts_mimi_encode_batch.restype = ci; L.ptts_mimi_encode_batch.argtypes = [vp, C.POINTER(vp), ci, ci, C.POINTER(vp), ci]
     L.ptts_phase_timing.restype = ci; L.ptts_phase_timing.argtypes = [vp, ci]
     L.ptts_phase_times.restype = ci; L.ptts_phase_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.ptts_scheduler_stats.restype = ci; L.ptts_scheduler_stats.argtypes = [vp, C.POINTER(C.c_long)]
@@ -322,6 +323,18 @@ class Engine:
         out = np.empty((cap, self.d_model), np.float32)
         n = _check(self.L.ptts_mimi_encode(self.h, audio, len(audio), out, cap), "mimi_encode")
         return out[:n].copy()
+
+    def mimi_encode_batch(self, clips) -> List[np.ndarray]:
+        """Equal-length clips through the encoder together (stacked along the row dimension)."""
+        keep = [np.ascontiguousarray(c, np.float32) for c in clips]
+        n, samples = len(keep), len(keep[0])
+        assert all(len(c) == samples for c in keep)
+        cap = samples // max(self.frame_size, 1) + 4
+        outs = [np.empty((cap, self.d_model), np.float32) for _ in range(n)]
+        cp = (C.c_void_p * n)(*[c.ctypes.data for c in keep])
+        op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        rows = _check(self.L.ptts_mimi_encode_batch(self.h, cp, n, samples, op, cap), "mimi_encode_batch")
+        return [o[:rows].copy() for o in outs]
 
     # ---- whole path ----
     def generate_ids(self, ids_list: Sequence[np.ndarray], voices: Sequence[np.ndarray],

@@ -78,6 +78,19 @@ def test_voice_encoder_5s_clip_and_truncated_10s_input(env):
     _note(f"fp32 full size voice encoder, 120000-sample clip: max-abs relative to the largest output {rel5:.3e}; "
           f"240000-sample input normalised then truncated to 120000: {rel10:.3e}")
     assert rel5 <= 1e-3 and rel10 <= 1e-3
+    # eight different 5 s clips through the encoder together: every clip equals the oracle's encoding of that clip
+    batch = [_clip(120000, 10 + i) * np.float32(0.5 + 0.1 * i) for i in range(8)]
+    got8 = eng.mimi_encode_batch(batch)
+    rel8 = 0.0
+    for i in (0, 3, 7):
+        w = o.mimi_encode(batch[i])
+        assert got8[i].shape == w.shape
+        rel8 = max(rel8, float(np.abs(got8[i] - w).max()) / max(float(np.abs(w).max()), 1.0))
+    for i in range(8):   # and the batch agrees with the clip encoded alone
+        alone = eng.mimi_encode(batch[i])
+        rel8 = max(rel8, float(np.abs(got8[i] - alone).max()) / max(float(np.abs(alone).max()), 1.0))
+    _note(f"fp32 full size voice encoder, 8 clips of 120000 samples stacked: max-abs relative to the largest output {rel8:.3e}")
+    assert rel8 <= 1e-3
     eng.close()
 
 
