@@ -209,7 +209,42 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
             frag_[n] = extra_.back().p;
         }
     }
-    {   // the voice encoder always runs on f32 weights
+    // The voice encoder keeps f32 accuracy at every precision setting (src/pocket_tts.cpp:92).  Its matrices are held as two
+    // bf16 terms each, W = hi + lo to ~16 mantissa bits, and multiplied by activations split the same way: three bf16 MFMAs
+    // per tile (hi hi, lo hi, hi lo) in place of one f32 MFMA at a sixteenth of the bf16 rate.  POCKET_TTS_ENCODER_F32=1
+    // keeps the f32 matrices and the f32 MFMA.
+    if (!std::getenv("POCKET_TTS_ENCODER_F32") && s.n_filters % 8 == 0 && s.mimi_dim % 8 == 0 && s.d_model % 4 == 0) {
+        std::vector<std::string> mats = {"enc.final.w", "enc.spk_proj.w"};
+        for (int i = 0; i < 3; ++i)
+            for (const char* t : {"res.c1.w", "res.c2.w", "down.w"}) mats.push_back("enc.s" + std::to_string(i) + "." + t);
+        for (int i = 0; i < s.mimi_layers; ++i)
+            for (const char* t : {"qkv.w", "out.w", "ff1.w", "ff2.w"}) mats.push_back("enc.t" + std::to_string(i) + "." + t);
+        for (auto& n : mats) {
+            const HostTensor& t = pack.get(n);
+            if (t.shape.size() != 2 || t.shape[1] % 8) continue;
+            const size_t el = t.numel();
+            std::vector<uint16_t> hi(el), lo(el);
+            auto to_bf16 = [](float v) {   // round to nearest even, as the device conversion does
+                uint32_t u; std::memcpy(&u, &v, 4);
+                if ((u & 0x7f800000u) == 0x7f800000u) return static_cast<uint16_t>(u >> 16);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                return static_cast<uint16_t>(u >> 16);
+            };
+            for (size_t i = 0; i < el; ++i) {
+                hi[i] = to_bf16(t.data[i]);
+                const uint32_t hu = static_cast<uint32_t>(hi[i]) << 16;
+                float hf; std::memcpy(&hf, &hu, 4);
+                lo[i] = to_bf16(t.data[i] - hf);
+            }
+            extra_.emplace_back(el * 2);
+            PTTS_HIP(hipMemcpy(extra_.back().p, hi.data(), el * 2, hipMemcpyHostToDevice));
+            const void* ph = extra_.back().p;
+            extra_.emplace_back(el * 2);
+            PTTS_HIP(hipMemcpy(extra_.back().p, lo.data(), el * 2, hipMemcpyHostToDevice));
+            split_[n] = {ph, extra_.back().p};
+        }
+    }
+    {   // the encoder's down-sampling product stays on f32 weights (skinny kernel, fragment-major)
         const HostTensor& t = pack.get("enc.down.w");
         if (t.shape.size() == 2 && t.shape[0] % 16 == 0 && t.shape[1] % 16 == 0) {
             auto bytes = pack_flow_weight(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), W_F32);
@@ -244,6 +279,14 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     }
 }
 
+void DevWeight::bind(GemmArgs& g, int M) const {
+    g.W = p; g.wtype = wtype; g.W2 = nullptr;
+    if (!lo) return;
+    const long long tiles = static_cast<long long>((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles >= 128 || !f32) { g.W2 = lo; g.split_a = 1; }
+    else { g.W = f32; g.wtype = W_F32; g.split_a = 0; }
+}
+
 const float* Model::f(const std::string& name) const {
     auto it = entries_.find(name);
     if (it == entries_.end()) throw std::runtime_error("model: unknown tensor " + name);
@@ -267,6 +310,8 @@ DevWeight Model::w(const std::string& name) const {
     }
     auto fr = frag_.find(name);
     if (fr != frag_.end()) d.frag = fr->second;
+    auto sp = split_.find(name);
+    if (sp != split_.end()) { d.f32 = d.p; d.p = sp->second.first; d.lo = sp->second.second; d.wtype = W_BF16; }
     return d;
 }
 
@@ -746,6 +791,7 @@ void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc,
         GemmArgs g;
         g.A = b.h; g.lda = d; g.W = w.qkv.p; g.wtype = w.qkv.wtype; g.C = b.qkv; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d;
         g.split_a = split_a; g.a_bf16 = bfr;
+        if (w.qkv.lo) w.qkv.bind(g, M);
         if (thin) thin_linear(w.qkv, b.h, d, b.qkv, 3 * d, 3 * d, d, ACT_NONE, nullptr, nullptr, 0);
         else launch_gemm(g, st);
         RopeAppendArgs r;
@@ -761,6 +807,7 @@ void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc,
         GemmArgs o;
         o.A = b.att; o.lda = d; o.W = w.out.p; o.wtype = w.out.wtype; o.C = X; o.ldc = d; o.R = X; o.ldr = d; o.colscale = w.ls1;
         o.M = M; o.N = d; o.K = d; o.split_a = split_a;
+        if (w.out.lo) w.out.bind(o, M);
         if (thin) thin_linear(w.out, b.att, d, X, d, d, d, ACT_NONE, w.ls1, X, d);
         else launch_gemm(o, st);
         ln.g = w.ln2g; ln.b = w.ln2b;
@@ -768,11 +815,13 @@ void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc,
         GemmArgs f1;
         f1.A = b.h; f1.lda = d; f1.W = w.ff1.p; f1.wtype = w.ff1.wtype; f1.C = b.ff; f1.ldc = ffn; f1.act_pre = ACT_GELU;
         f1.M = M; f1.N = ffn; f1.K = d; f1.split_a = split_a; f1.a_bf16 = bfr; f1.c_bf16 = bfr;
+        if (w.ff1.lo) w.ff1.bind(f1, M);
         if (thin) thin_linear(w.ff1, b.h, d, b.ff, ffn, ffn, d, ACT_GELU, nullptr, nullptr, 0);
         else launch_gemm(f1, st);
         GemmArgs f2;
         f2.A = b.ff; f2.lda = ffn; f2.W = w.ff2.p; f2.wtype = w.ff2.wtype; f2.R = X; f2.ldr = d; f2.colscale = w.ls2;
         f2.M = M; f2.N = d; f2.K = ffn; f2.split_a = split_a; f2.a_bf16 = bfr;
+        if (w.ff2.lo) w.ff2.bind(f2, M);
         if (last_out && l + 1 == layers.size()) {
             f2.C = last_out; f2.c_bs = last_bs; f2.ldc = last_ld; f2.rpb = rpb;
             f2.r_bs = (long long)rpb * d; f2.a_bs = (long long)rpb * ffn;

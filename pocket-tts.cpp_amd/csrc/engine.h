@@ -45,6 +45,11 @@ struct DevWeight {
     int wtype = W_F32;
     int N = 0, K = 0;
     const void* frag = nullptr;   // fragment-major copy for the skinny kernels (same type), where the model keeps one
+    const void* lo = nullptr;     // W_BF16 with a second term: bf16(W - bf16(W)); p holds bf16(W)  (the voice encoder's matrices)
+    const void* f32 = nullptr;    // ... and the f32 matrix itself, for products too small to fill the chip with 128 x 128 tiles
+    // operand choice for a product of M rows: two bf16 terms when its 128 x 128 tiles give at least half the CUs a
+    // workgroup, the f32 matrix (64 x 64 tiles, f32 MFMA) below that
+    void bind(struct GemmArgs& g, int M) const;
 };
 
 struct TfLayer {
@@ -92,6 +97,7 @@ private:
     DevBuf blob_f32_, blob_lp_, rope_;
     std::vector<DevBuf> extra_;
     std::map<std::string, const void*> frag_;   // fragment-major copies by tensor name
+    std::map<std::string, std::pair<const void*, const void*>> split_;   // two-term bf16 copies (hi, lo) by tensor name
 };
 
 struct EngineOptions {

@@ -574,8 +574,9 @@ void Engine::encode_clips(const float* const* clips, int B, int S, std::vector<s
         float* h1 = take(Bz * T * (c / 2));
         GemmArgs c1;
         c1.A = xe; c1.lda = c; c1.a_bs = static_cast<long long>(xe_seg) * c; c1.rpb = T;
-        c1.W = hd_.enc_c1[i].p; c1.wtype = hd_.enc_c1[i].wtype; c1.bias = hd_.enc_c1_b[i];
+         c1.bias = hd_.enc_c1_b[i];
         c1.M = B * T; c1.N = c / 2; c1.K = rk * c; c1.C = h1; c1.ldc = c / 2; c1.c_bs = static_cast<long long>(T) * (c / 2); c1.c_act = ACT_ELU;
+        hd_.enc_c1[i].bind(c1, c1.M);
         launch_gemm(c1, stream_);
         // rows [r, r + T) of a clip's segment are written by the product below; the padding before and after them stays zero
         const size_t ye_seg = static_cast<size_t>(r + Tpad);
@@ -584,9 +585,10 @@ void Engine::encode_clips(const float* const* clips, int B, int S, std::vector<s
         zero_rows(ye, ye_seg, static_cast<size_t>(r + T), static_cast<size_t>(Tpad - T), c);
         GemmArgs c2;
         c2.A = h1; c2.lda = c / 2; c2.a_bs = static_cast<long long>(T) * (c / 2); c2.rpb = T;
-        c2.W = hd_.enc_c2[i].p; c2.wtype = hd_.enc_c2[i].wtype; c2.bias = hd_.enc_c2_b[i];
+         c2.bias = hd_.enc_c2_b[i];
         c2.M = B * T; c2.N = c; c2.K = c / 2; c2.R = xraw; c2.ldr = c; c2.r_bs = static_cast<long long>(T) * c;
         c2.C = ye + static_cast<size_t>(r) * c; c2.ldc = c; c2.c_bs = static_cast<long long>(ye_seg) * c; c2.c_act = ACT_ELU;
+        hd_.enc_c2[i].bind(c2, c2.M);
         launch_gemm(c2, stream_);
         const int pn = i < 2 ? rk - 1 : lk - 1;
         float* xraw2 = take(Bz * To * 2 * c);
@@ -595,9 +597,10 @@ void Engine::encode_clips(const float* const* clips, int B, int S, std::vector<s
         zero_rows(xe2, xe2_seg, 0, pn, 2 * c);
         GemmArgs dn;
         dn.A = ye; dn.lda = r * c; dn.a_bs = static_cast<long long>(ye_seg) * c; dn.rpb = To;
-        dn.W = hd_.enc_down[i].p; dn.wtype = hd_.enc_down[i].wtype; dn.bias = hd_.enc_down_b[i];
+         dn.bias = hd_.enc_down_b[i];
         dn.M = B * To; dn.N = 2 * c; dn.K = 2 * r * c; dn.C = xraw2; dn.ldc = 2 * c; dn.c_bs = static_cast<long long>(To) * 2 * c;
         dn.C2 = xe2 + static_cast<size_t>(pn) * 2 * c; dn.ldc2 = 2 * c; dn.c2_bs = static_cast<long long>(xe2_seg) * 2 * c; dn.c2_act = ACT_ELU;
+        hd_.enc_down[i].bind(dn, dn.M);
         launch_gemm(dn, stream_);
         xraw = xraw2;
         xe = xe2; xe_seg = xe2_seg; xe_pad = pn;
@@ -606,8 +609,9 @@ void Engine::encode_clips(const float* const* clips, int B, int S, std::vector<s
     float* y = take(Bz * T * M);
     GemmArgs fin;
     fin.A = xe; fin.lda = c; fin.a_bs = static_cast<long long>(xe_seg) * c; fin.rpb = T;
-    fin.W = hd_.enc_final.p; fin.wtype = hd_.enc_final.wtype; fin.bias = hd_.enc_final_b;
+     fin.bias = hd_.enc_final_b;
     fin.M = B * T; fin.N = M; fin.K = lk * c; fin.C = y; fin.ldc = M; fin.c_bs = static_cast<long long>(T) * M;
+    hd_.enc_final.bind(fin, fin.M);
     launch_gemm(fin, stream_);
     // transformer over every clip from position 0 (attention per clip)
     const int Nv = (T + U - 1) / U, Tpad = Nv * U;
@@ -650,7 +654,8 @@ void Engine::encode_clips(const float* const* clips, int B, int S, std::vector<s
         launch_gemm(ds, stream_);
     }
     GemmArgs sp;
-    sp.A = d2; sp.lda = M; sp.W = hd_.enc_spk.p; sp.wtype = hd_.enc_spk.wtype; sp.M = rows; sp.N = D; sp.K = M; sp.C = o; sp.ldc = D;
+    sp.A = d2; sp.lda = M;  sp.M = rows; sp.N = D; sp.K = M; sp.C = o; sp.ldc = D;
+    hd_.enc_spk.bind(sp, sp.M);
     launch_gemm(sp, stream_);
     check_launches("the voice encoder");
     out.assign(Bz, std::vector<float>(static_cast<size_t>(Nv) * D));

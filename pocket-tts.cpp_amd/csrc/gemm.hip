@@ -215,6 +215,7 @@ void launch_gemm(const GemmArgs& a, hipStream_t s) {
         if (gemm_lean_eligible(l)) { launch_gemm_lean(l, s); return; }
     }
     if (a.a_bf16 || a.c_bf16) throw std::runtime_error("gemm: bf16 activation rows are only handled by the lean kernel (shape or options not eligible)");
+    if (a.W2) throw std::runtime_error("gemm: two-term bf16 weights are only handled by the lean kernel (shape or options not eligible)");
     if (a.K <= 0 || (a.K & 3) || (a.lda & 3) || (a.a_bs & 3) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15))
         throw std::runtime_error("gemm: K, lda and batch stride must be multiples of 4 floats and pointers 16-byte aligned");
     if (a.wtype == W_BF16 && (a.K & 7)) throw std::runtime_error("gemm: bf16 weights need K % 8 == 0");

@@ -34,11 +34,13 @@ constexpr int LBM = 128, LBN = 128, LBK = 64, LLD = LBK + 8;
 
 // SPLIT (f32 A only): A is staged as two bf16 terms, hi = bf16(a) and lo = bf16(a - hi), and every weight fragment
 // meets both, so the product carries the activation to ~16 mantissa bits (the latent path's prefill).
-template <bool ABF, bool CBF, bool SPLIT>
+// WSPLIT (with SPLIT): the weights come as two bf16 terms as well (a.W, a.W2); the third MFMA adds A_hi W_lo.
+template <bool ABF, bool CBF, bool SPLIT, bool WSPLIT = false>
 __global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 As[LBM * LLD];
     __shared__ __attribute__((aligned(16))) __bf16 Al[SPLIT ? LBM * LLD : 8];
     __shared__ __attribute__((aligned(16))) __bf16 Ws[LBN * LLD];
+    __shared__ __attribute__((aligned(16))) __bf16 Wl[WSPLIT ? LBN * LLD : 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = blockIdx.x * LBM, n0 = blockIdx.y * LBN;
@@ -69,7 +71,8 @@ __global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a) {
         wk[i] = p * 8;
         wptr[i] = (n0 + row < N) ? (const __bf16*)a.W + (long long)(n0 + row) * K + p * 8 : nullptr;
     }
-    uint4 areg[APT], wreg[WPT];
+    uint4 areg[APT], wreg[WPT], wreg2[WSPLIT ? WPT : 1];
+    const long long w2_off = WSPLIT ? (const char*)a.W2 - (const char*)a.W : 0;
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < APT; ++i)
@@ -77,6 +80,11 @@ __global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
             wreg[i] = (wptr[i] && k0 + wk[i] < K) ? *(const uint4*)(wptr[i] + k0) : make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (WSPLIT) {
+#pragma unroll
+            for (int i = 0; i < WPT; ++i)
+                wreg2[i] = (wptr[i] && k0 + wk[i] < K) ? *(const uint4*)((const char*)(wptr[i] + k0) + w2_off) : make_uint4(0u, 0u, 0u, 0u);
+        }
     };
     auto store_tiles = [&]() {
 #pragma unroll
@@ -111,6 +119,7 @@ __global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a) {
         for (int i = 0; i < WPT; ++i) {
             const int id = tid + 256 * i, row = id >> 3, p = id & 7;
             *(uint4*)&Ws[row * LLD + p * 8] = wreg[i];
+            if constexpr (WSPLIT) *(uint4*)&Wl[row * LLD + p * 8] = wreg2[i];
         }
     };
 
@@ -130,18 +139,22 @@ __global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a) {
         if (k0 + LBK < K) load_tiles(k0 + LBK);
 #pragma unroll
         for (int ks = 0; ks < LBK / 16; ++ks) {
-            bf16x8 af[2], al[2], wf[2];
+            bf16x8 af[2], al[2], wf[2], wl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 af[i] = *(const bf16x8*)&As[(wr * 64 + i * 32 + lr) * LLD + ks * 16 + lh * 8];
                 if constexpr (SPLIT) al[i] = *(const bf16x8*)&Al[(wr * 64 + i * 32 + lr) * LLD + ks * 16 + lh * 8];
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) wf[j] = *(const bf16x8*)&Ws[(wc * 64 + j * 32 + lr) * LLD + ks * 16 + lh * 8];
+            for (int j = 0; j < 2; ++j) {
+                wf[j] = *(const bf16x8*)&Ws[(wc * 64 + j * 32 + lr) * LLD + ks * 16 + lh * 8];
+                if constexpr (WSPLIT) wl[j] = *(const bf16x8*)&Wl[(wc * 64 + j * 32 + lr) * LLD + ks * 16 + lh * 8];
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+                    if constexpr (WSPLIT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[j], af[i], acc[i][j], 0, 0, 0);
                     if constexpr (SPLIT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], al[i], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);   // C^T tile
                 }
@@ -208,8 +221,9 @@ __global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a) {
 bool gemm_lean_eligible(const GemmArgs& a) {
     if (a.wtype != W_BF16 || a.G || a.act_pre != ACT_NONE) return false;
     if (a.split_a && (a.a_bf16 || a.c_bf16)) return false;
-    // small problems: the 64 x 64 tiles of the general kernel fill the chip better (bf16 rows exist only here)
-    if (!(a.a_bf16 || a.c_bf16) && (a.M < 512 || a.N < 32)) return false;
+    if (a.W2 && (!a.split_a || ((uintptr_t)a.W2 & 15))) return false;
+    // small problems: the 64 x 64 tiles of the general kernel fill the chip better (bf16 rows and two-term weights exist only here)
+    if (!(a.a_bf16 || a.c_bf16 || a.W2) && (a.M < 512 || a.N < 32)) return false;
     if ((a.N & 3) || (a.K & 7) || (a.ldc & 3) || (a.c_bs & 3)) return false;
     const int ael = a.a_bf16 ? 8 : 4;
     if ((a.lda % ael) || (a.a_bs % ael) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15)) return false;
@@ -223,7 +237,9 @@ bool gemm_lean_eligible(const GemmArgs& a) {
 
 void launch_gemm_lean(const GemmArgs& a, hipStream_t s) {
     dim3 grid((a.M + LBM - 1) / LBM, (a.N + LBN - 1) / LBN), block(256);
-    if (a.split_a) {
+    if (a.split_a && a.W2) {
+        hipLaunchKernelGGL((gemm_lean_kernel<false, false, true, true>), grid, block, 0, s, a);
+    } else if (a.split_a) {
         hipLaunchKernelGGL((gemm_lean_kernel<false, false, true>), grid, block, 0, s, a);
     } else if (a.a_bf16) {
         if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<true, true, false>), grid, block, 0, s, a);

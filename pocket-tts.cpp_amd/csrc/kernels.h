@@ -32,6 +32,10 @@ struct GemmArgs {
     int a_act = ACT_NONE, act_pre = ACT_NONE;
     int a_bf16 = 0, c_bf16 = 0;   // A rows / C rows are bf16 in memory (bf16 weights only; strides count elements)
     int split_a = 0;  // bf16 weights only: stage A as hi + lo bf16 terms (two MFMAs per tile) instead of rounding it once
+    // bf16 weights only, with split_a: the second bf16 term of the weights, W2 = bf16(W - bf16(W)).  The product then carries
+    // both operands to ~16 mantissa bits (A_hi W_hi + A_lo W_hi + A_hi W_lo, f32 accumulation): f32-grade results from three
+    // bf16 MFMAs, at a third of the bf16 rate instead of the f32 MFMA's sixteenth.
+    const void* W2 = nullptr;
 };
 void launch_gemm(const GemmArgs& a, hipStream_t s);
 
