@@ -283,7 +283,7 @@ void DevWeight::bind(GemmArgs& g, int M) const {
     g.W = p; g.wtype = wtype; g.W2 = nullptr;
     if (!lo) return;
     const long long tiles = static_cast<long long>((M + 127) / 128) * ((N + 127) / 128);
-    if (tiles >= 128 || !f32) { g.W2 = lo; g.split_a = 1; }
+    if ((tiles >= 128 && N >= 128) || !f32) { g.W2 = lo; g.split_a = 1; }   // below 128 columns half of every tile would be idle
     else { g.W = f32; g.wtype = W_F32; g.split_a = 0; }
 }
 
@@ -677,7 +677,11 @@ Engine::~Engine() {
     batch_pool_.clear();
     drop_table();
     PTTS_TRACE("dtor: table dropped");
-    if (enc_pin_) (void)hipHostFree(enc_pin_);
+    for (auto& E : enc_slot_) {
+        if (E.pin_in) (void)hipHostFree(E.pin_in);
+        if (E.pin_out) (void)hipHostFree(E.pin_out);
+        if (E.done) (void)hipEventDestroy(E.done);
+    }
     for (auto& pe : pending_events_) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     if (ev_[0]) (void)hipEventDestroy(ev_[0]);
     if (ev_[1]) (void)hipEventDestroy(ev_[1]);

@@ -197,6 +197,8 @@ public:
     // Voice encoder: audio f32[S] at the model rate -> [frames][d_model]  (src/pocket_tts.cpp:261-291)
     std::vector<float> encode_voice(const float* audio, int S);
     void encode_clips(const float* const* clips, int B, int S, std::vector<std::vector<float>>& out);
+    void encode_enqueue(const float* const* clips, int B, int S, int slot);
+    void encode_collect(int slot, std::vector<std::vector<float>>& out);
     void encode_voice_batch(const std::vector<const float*>& clips, const std::vector<int>& lens,
                             std::vector<std::vector<float>>& out);
 
@@ -280,9 +282,15 @@ private:
     unsigned char* static_scratch_ = nullptr;   // this device's copy of the static scratch array (noalloc.cpp)
     void init_static_scratch();
     DevBuf flow_te_;  // [lsd_steps][C] averaged time embeddings of the fixed (s_j, t_j) grid
-    DevBuf enc_arena_;   // every buffer of a voice-encoder pass, kept between calls
-    float* enc_pin_ = nullptr;   // pinned staging of a pass's clips
-    size_t enc_pin_bytes_ = 0;
+    struct EncSlot {             // buffers of one voice-encoder pass, kept between calls
+        DevBuf arena;            // every device buffer of the pass
+        float* pin_in = nullptr; size_t pin_in_bytes = 0;      // pinned staging of the clips
+        float* pin_out = nullptr; size_t pin_out_bytes = 0;    // pinned landing area of the embeddings
+        hipEvent_t done = nullptr;
+        int clips = 0; size_t row_floats = 0;
+    };
+    EncSlot enc_slot_[2];
+    std::mutex enc_mu_;
     std::map<std::pair<int, int>, std::unique_ptr<Batch>> batch_pool_;   // (rows, lane)
     std::vector<hipStream_t> lane_streams_;     // lane 0 = stream_
     std::vector<hipEvent_t> lane_events_;

@@ -499,13 +499,33 @@ std::vector<float> Engine::encode_voice(const float* audio, int S) {
     return std::move(out[0]);
 }
 
-// B clips of S samples each -> B embeddings [ceil(frames)][d_model] (src/pocket_tts.cpp:241-297 for one clip).
+void Engine::encode_clips(const float* const* clips, int B, int S, std::vector<std::vector<float>>& out) {
+    std::lock_guard<std::mutex> order(enc_mu_);
+    encode_enqueue(clips, B, S, 0);
+    encode_collect(0, out);
+}
+
+// The results of the pass enqueued on `slot`, once its copy to pinned memory has landed.
+void Engine::encode_collect(int slot, std::vector<std::vector<float>>& out) {
+    EncSlot& E = enc_slot_[slot];
+    PTTS_HIP(hipEventSynchronize(E.done));
+    out.assign(static_cast<size_t>(E.clips), std::vector<float>(E.row_floats));
+    for (int b = 0; b < E.clips; ++b) std::memcpy(out[b].data(), E.pin_out + static_cast<size_t>(b) * E.row_floats, E.row_floats * 4);
+}
+
+// B clips of S samples each -> B embeddings [ceil(frames)][d_model] (src/pocket_tts.cpp:241-297 for one clip), enqueued on
+// the engine stream with the buffers of `slot` (two slots: the host side of one pass overlaps the GPU side of the other).
 // The clips are stacked along the row dimension of every product: the SEANet stages and the transformer's linear layers
 // see B times the rows (at one clip the stages behind the second down-sampling run a few hundred workgroups or fewer),
 // attention runs per clip.
-void Engine::encode_clips(const float* const* clips, int B, int S, std::vector<std::vector<float>>& out) {
+void Engine::encode_enqueue(const float* const* clips, int B, int S, int slot) {
     std::lock_guard<std::mutex> guard(mu_);
     PTTS_HIP(hipSetDevice(opt_.device));
+    EncSlot& E = enc_slot_[slot];
+    DevBuf& enc_arena_ = E.arena;
+    float*& enc_pin_ = E.pin_in;
+    size_t& enc_pin_bytes_ = E.pin_in_bytes;
+    if (!E.done) PTTS_HIP(hipEventCreateWithFlags(&E.done, hipEventDisableTiming));
     const Spec& s = spec();
     if (S <= 0 || B <= 0) throw std::runtime_error("voice clip is empty");
     const int M = s.mimi_dim, U = s.upsample, D = s.d_model, rk = s.res_kernel, lk = s.last_kernel;
@@ -658,28 +678,46 @@ void Engine::encode_clips(const float* const* clips, int B, int S, std::vector<s
     hd_.enc_spk.bind(sp, sp.M);
     launch_gemm(sp, stream_);
     check_launches("the voice encoder");
-    out.assign(Bz, std::vector<float>(static_cast<size_t>(Nv) * D));
-    for (int b = 0; b < B; ++b)
-        PTTS_HIP(hipMemcpyAsync(out[b].data(), o + static_cast<size_t>(b) * seg * D, out[b].size() * 4, hipMemcpyDeviceToHost, stream_));
-    PTTS_HIP(hipStreamSynchronize(stream_));
+    const size_t row_floats = static_cast<size_t>(Nv) * D;
+    if (E.pin_out_bytes < Bz * row_floats * 4) {
+        if (E.pin_out) PTTS_HIP(hipHostFree(E.pin_out));
+        E.pin_out = nullptr; E.pin_out_bytes = 0;
+        PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&E.pin_out), Bz * row_floats * 4));
+        E.pin_out_bytes = Bz * row_floats * 4;
+    }
+    PTTS_HIP(hipMemcpy2DAsync(E.pin_out, row_floats * 4, o, static_cast<size_t>(seg) * D * 4, row_floats * 4, Bz, hipMemcpyDeviceToHost, stream_));
+    PTTS_HIP(hipEventRecord(E.done, stream_));
+    E.clips = B; E.row_floats = row_floats;
 }
 
-// Clips of equal length go through the encoder together, up to POCKET_TTS_ENCODE_BATCH (default 8) at a time.
+// Clips of equal length go through the encoder together, up to POCKET_TTS_ENCODE_BATCH (default 8) at a time; while one
+// group runs on the GPU the next one is staged and enqueued.
 void Engine::encode_voice_batch(const std::vector<const float*>& clips, const std::vector<int>& lens, std::vector<std::vector<float>>& out) {
     static const int max_b = [] { const char* e = std::getenv("POCKET_TTS_ENCODE_BATCH"); return e ? std::max(1, std::min(64, std::atoi(e))) : 8; }();
     out.assign(clips.size(), std::vector<float>());
     std::vector<char> done(clips.size(), 0);
+    std::vector<std::vector<size_t>> groups;
     for (size_t i = 0; i < clips.size(); ++i) {
         if (done[i]) continue;
         std::vector<size_t> group{i};
+        done[i] = 1;
         for (size_t j = i + 1; j < clips.size() && group.size() < static_cast<size_t>(max_b); ++j)
-            if (!done[j] && lens[j] == lens[i]) group.push_back(j);
-        std::vector<const float*> ptrs;
-        for (size_t g : group) { ptrs.push_back(clips[g]); done[g] = 1; }
-        std::vector<std::vector<float>> part;
-        encode_clips(ptrs.data(), static_cast<int>(ptrs.size()), lens[i], part);
-        for (size_t k = 0; k < group.size(); ++k) out[group[k]] = std::move(part[k]);
+            if (!done[j] && lens[j] == lens[i]) { group.push_back(j); done[j] = 1; }
+        groups.push_back(std::move(group));
     }
+    std::lock_guard<std::mutex> order(enc_mu_);   // one caller's groups at a time own the two slots
+    auto collect = [&](size_t g) {
+        std::vector<std::vector<float>> part;
+        encode_collect(static_cast<int>(g & 1), part);
+        for (size_t k = 0; k < groups[g].size(); ++k) out[groups[g][k]] = std::move(part[k]);
+    };
+    for (size_t g = 0; g < groups.size(); ++g) {
+        std::vector<const float*> ptrs;
+        for (size_t idx : groups[g]) ptrs.push_back(clips[idx]);
+        if (g >= 2) collect(g - 2);   // the slot about to be reused
+        encode_enqueue(ptrs.data(), static_cast<int>(ptrs.size()), lens[groups[g][0]], static_cast<int>(g & 1));
+    }
+    for (size_t g = groups.size() >= 2 ? groups.size() - 2 : 0; g < groups.size(); ++g) collect(g);
 }
 
 // ------------------------------------------------------------------------------------------ graph-level entry points

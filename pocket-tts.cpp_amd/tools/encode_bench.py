@@ -13,7 +13,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=64)
     ap.add_argument("--samples", type=int, default=120000)
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=32, help="clips per call (the library stacks them 8 at a time)")
     args = ap.parse_args()
     import ptts_pack as pp
     import ptts_lib
