@@ -755,6 +755,18 @@ Batch* Engine::acquire_batch(int B, int lane) {
     const bool fresh = it == batch_pool_.end();
     if (fresh) it = batch_pool_.emplace(key, std::make_unique<Batch>(*this, B)).first;
     Batch* b = it->second.get();
+    // most recently used first; beyond kMaxPooled sizes the least recently used one that the staged job does not hold is freed
+    batch_lru_.remove(key);
+    batch_lru_.push_front(key);
+    for (auto old = batch_lru_.end(); batch_pool_.size() > kMaxPooled && old != batch_lru_.begin();) {
+        --old;
+        auto victim = batch_pool_.find(*old);
+        const bool held = victim == it || std::find(job_.parts.begin(), job_.parts.end(), victim->second.get()) != job_.parts.end();
+        if (held) continue;
+        (void)hipStreamSynchronize(victim->second->st ? victim->second->st : stream_);
+        batch_pool_.erase(victim);
+        old = batch_lru_.erase(old);
+    }
     b->st = lane_streams_[lane];
     b->ready = lane_events_[lane];
     b->dec_st = dec_stream_;

@@ -12,6 +12,7 @@
 #include <deque>
 #include <exception>
 #include <functional>
+#include <list>
 #include <map>
 #include <mutex>
 #include <random>
@@ -292,6 +293,8 @@ private:
     EncSlot enc_slot_[2];
     std::mutex enc_mu_;
     std::map<std::pair<int, int>, std::unique_ptr<Batch>> batch_pool_;   // (rows, lane)
+    std::list<std::pair<int, int>> batch_lru_;                           // keys of batch_pool_, most recently used first
+    static constexpr size_t kMaxPooled = 8;                              // batch sizes kept warm per engine
     std::vector<hipStream_t> lane_streams_;     // lane 0 = stream_
     std::vector<hipEvent_t> lane_events_;
     bool lane_shared_decoder_ = false;          // parts > 1: decoder chunks on dec_stream_ instead of the lane's own stream
