@@ -155,6 +155,9 @@ POCKET_TTS_API int ptts_audio_normalize(const float* in, int n, float* out);
  * output row to int8 and A per row and per block of 64 k (K % 64 == 0, N % 16 == 0).  For checking the kernel's
  * arithmetic exactly; the model paths call the same kernel. */
 POCKET_TTS_API int ptts_q8_linear(PocketTTSHandle handle, const float* A, int M, int K, const float* W, int N, float* out);
+/* The same with the matrix given in int8 form, q[N][K] and one scale per output row (what a pack's `<name>.q8` carries). */
+POCKET_TTS_API int ptts_q8_linear_q(PocketTTSHandle handle, const float* A, int M, int K, const signed char* q, const float* scale, int N,
+                                    float* out);
 
 /* The bf16-weight matrix product on its own: out[M][N] = act(A . W^T + bias) * colscale + R (bias, colscale, R may be
  * NULL; act: 0 none, 1 GELU, 2 SiLU, 3 ELU; W is rounded to bf16).  flags bit 0: carry A as two bf16 terms; bit 1: keep

@@ -49,6 +49,14 @@ struct HostTensor {
     }
 };
 
+// int8 form of a matrix carried by the pack beside its f32 tensor (`<name>.q8`, `<name>.q8s`): values [N][K] and one
+// scale per output row, W ~ q * scale.
+struct Q8Tensor {
+    const int8_t* q = nullptr;
+    const float* scale = nullptr;
+    int N = 0, K = 0;
+};
+
 // Read-only view of a .ptts weight pack held in host memory.
 class Pack {
 public:
@@ -56,11 +64,16 @@ public:
     const Spec& spec() const { return spec_; }
     const HostTensor& get(const std::string& name) const;
     bool has(const std::string& name) const { return tensors_.count(name) != 0; }
+    const Q8Tensor* q8(const std::string& name) const {
+        auto it = q8_.find(name);
+        return it == q8_.end() ? nullptr : &it->second;
+    }
 
 private:
     std::vector<unsigned char> blob_;
     Spec spec_;
     std::map<std::string, HostTensor> tensors_;
+    std::map<std::string, Q8Tensor> q8_;
 };
 
 // Owning device buffer.

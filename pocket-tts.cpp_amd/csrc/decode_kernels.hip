@@ -383,7 +383,6 @@ __global__ __launch_bounds__(256) void skinny_q8p_kernel(SkinnyArgs a) {
 // of output column nt*16 + (l&15).
 std::vector<unsigned char> pack_q8_weight(const float* W, int N, int K, std::vector<float>& scale) {
     if (N % 16 || K % 64) throw std::runtime_error("int8 weight: N must be a multiple of 16 and K of 64");
-    std::vector<unsigned char> out((size_t)N * K);
     scale.assign(N, 0.f);
     std::vector<signed char> q((size_t)N * K);
     for (int n = 0; n < N; ++n) {
@@ -397,6 +396,12 @@ std::vector<unsigned char> pack_q8_weight(const float* W, int N, int K, std::vec
             q[(size_t)n * K + k] = (signed char)rv;
         }
     }
+    return pack_q8_layout(q.data(), N, K);
+}
+
+std::vector<unsigned char> pack_q8_layout(const signed char* q, int N, int K) {
+    if (N % 16 || K % 64) throw std::runtime_error("int8 weight: N must be a multiple of 16 and K of 64");
+    std::vector<unsigned char> out((size_t)N * K);
     const int KS = K / 64;
     for (int nt = 0; nt < N / 16; ++nt)
         for (int ks = 0; ks < KS; ++ks)

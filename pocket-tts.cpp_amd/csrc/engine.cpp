@@ -161,7 +161,16 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     auto packed_q8 = [&](const std::string& name, const float*& scale_dev) -> const void* {
         const HostTensor& t = pack.get(name);
         std::vector<float> sc;
-        auto bytes = pack_q8_weight(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), sc);
+        std::vector<unsigned char> bytes;
+        // a matrix that is int8 at the source is used as it is (values and per-row scales); POCKET_TTS_REQUANTIZE=1
+        // quantises the f32 tensor again instead
+        const Q8Tensor* carried = std::getenv("POCKET_TTS_REQUANTIZE") ? nullptr : pack.q8(name);
+        if (carried) {
+            bytes = pack_q8_layout(reinterpret_cast<const signed char*>(carried->q), carried->N, carried->K);
+            sc.assign(carried->scale, carried->scale + carried->N);
+        } else {
+            bytes = pack_q8_weight(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), sc);
+        }
         extra_.emplace_back(bytes.size());
         PTTS_HIP(hipMemcpy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
         const void* wp = extra_.back().p;

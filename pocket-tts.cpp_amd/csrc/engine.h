@@ -215,7 +215,7 @@ public:
     void op_flow_euler_static(const float* cond_dev, const float* x0_dev, int B, float* x_out_dev);
     static size_t static_scratch_capacity();
     void op_mimi_decode(Batch* b, const float* latents /*[B][n][latent]*/, int n, float* audio /*[B][n*frame]*/);
-    void q8_linear(const float* A, int M, int K, const float* W, int N, float* out);   // the int8 product kernel alone
+    void q8_linear(const float* A, int M, int K, const float* W, int N, float* out, const signed char* q = nullptr, const float* qscale = nullptr);   // the int8 product kernel alone
     void bf16_linear(const float* A, int M, int K, const float* W, int N, const float* bias, const float* colscale, const float* R, int act,
                      int flags, float* out);   // the bf16 GEMM dispatch alone
 

@@ -761,11 +761,14 @@ void Engine::op_flow_euler(const float* cond, const float* x0, int B, float* x_o
     check_flow_ring(b.flow_ctl.as<unsigned>(), B);
 }
 
-void Engine::q8_linear(const float* A, int M, int K, const float* W, int N, float* out) {
+// W given: quantised here per output row; else q / qscale are the int8 values [N][K] and their per-row scales as they are.
+void Engine::q8_linear(const float* A, int M, int K, const float* W, int N, float* out, const signed char* q, const float* qscale) {
     std::lock_guard<std::mutex> guard(mu_);
     PTTS_HIP(hipSetDevice(opt_.device));
     std::vector<float> scale;
-    auto wq = pack_q8_weight(W, N, K, scale);
+    std::vector<unsigned char> wq;
+    if (W) wq = pack_q8_weight(W, N, K, scale);
+    else { wq = pack_q8_layout(q, N, K); scale.assign(qscale, qscale + N); }
     DevBuf dA(static_cast<size_t>(M) * K * 4), dW(wq.size()), dS(scale.size() * 4), dC(static_cast<size_t>(M) * N * 4);
     PTTS_HIP(hipMemcpyAsync(dA.p, A, dA.bytes, hipMemcpyHostToDevice, stream_));
     PTTS_HIP(hipMemcpyAsync(dW.p, wq.data(), wq.size(), hipMemcpyHostToDevice, stream_));

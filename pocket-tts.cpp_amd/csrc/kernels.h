@@ -216,6 +216,8 @@ std::vector<unsigned char> pack_flow_weight(const float* W, int N, int K, int wt
 // int8 form of the same layout (k-steps of 64, 16 values per lane): per output row n, scale[n] = max|W[n][:]| / 127
 // and q = rint(W * 127 / max) in [-127, 127].  K must be a multiple of 64.
 std::vector<unsigned char> pack_q8_weight(const float* W, int N, int K, std::vector<float>& scale);
+// The layout step alone, for int8 values that come with their own scales (a pack's `<name>.q8` form).
+std::vector<unsigned char> pack_q8_layout(const signed char* q, int N, int K);
 
 // ---- batched decode step (decode_kernels.hip) -----------------------------------------------------
 // C[M][N] = A[M][K] * W^T with f32 A and W fragment-major (pack_flow_weight layout, f32 or bf16).

@@ -73,8 +73,21 @@ Pack::Pack(const std::string& path) {
     for (uint32_t i = 0; i < n; ++i) {
         RawEntry e;
         std::memcpy(&e, blob_.data() + kHeaderSize + i * sizeof(RawEntry), sizeof(RawEntry));
-        if (e.dtype != 0) throw std::runtime_error("weight pack: only f32 tensors are supported");
+        if (e.dtype > 1) throw std::runtime_error("weight pack: unknown element type");
         if (e.offset + e.nbytes > blob_.size() || e.ndim > 4) throw std::runtime_error("weight pack: bad tensor entry");
+        if (e.dtype == 1) {   // int8 matrix "<name>.q8"
+            char qn[65];
+            std::memcpy(qn, e.name, 64);
+            qn[64] = 0;
+            std::string base(qn);
+            if (e.ndim != 2 || base.size() < 4 || base.compare(base.size() - 3, 3, ".q8") != 0 || e.nbytes != e.shape[0] * e.shape[1])
+                throw std::runtime_error("weight pack: bad int8 entry " + base);
+            Q8Tensor& q = q8_[base.substr(0, base.size() - 3)];
+            q.q = reinterpret_cast<const int8_t*>(blob_.data() + e.offset);
+            q.N = static_cast<int>(e.shape[0]);
+            q.K = static_cast<int>(e.shape[1]);
+            continue;
+        }
         HostTensor t;
         t.data = reinterpret_cast<const float*>(blob_.data() + e.offset);
         for (uint32_t d = 0; d < e.ndim; ++d) t.shape.push_back(static_cast<int64_t>(e.shape[d]));
@@ -82,6 +95,16 @@ Pack::Pack(const std::string& path) {
         std::memcpy(nm, e.name, 64);
         nm[64] = 0;
         tensors_[nm] = t;
+    }
+    // scales of the int8 forms; a form without its scales (or with the wrong count) is dropped with an error
+    for (auto it = q8_.begin(); it != q8_.end(); ++it) {
+        auto sc = tensors_.find(it->first + ".q8s");
+        if (sc == tensors_.end() || sc->second.numel() != static_cast<size_t>(it->second.N))
+            throw std::runtime_error("weight pack: int8 form of " + it->first + " has no matching scales");
+        it->second.scale = sc->second.data;
+        auto f = tensors_.find(it->first);
+        if (f == tensors_.end() || f->second.shape.size() != 2 || f->second.shape[0] != it->second.N || f->second.shape[1] != it->second.K)
+            throw std::runtime_error("weight pack: int8 form of " + it->first + " does not match its f32 tensor");
     }
 }
 

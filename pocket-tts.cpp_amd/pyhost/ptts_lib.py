@@ -51,7 +51,7 @@ EXT_SYMBOLS = [
     "pocket_tts_stage_ids", "pocket_tts_run_staged", "pocket_tts_fetch_staged",
     "pocket_tts_tokenize", "ptts_text_conditioner", "ptts_state_new", "ptts_state_free", "ptts_state_reset",
     "ptts_lm_prefill", "ptts_lm_step", "ptts_flow_euler", "ptts_flow_euler_noalloc", "ptts_flow_euler_noalloc_capacity", "ptts_mimi_decode", "ptts_mimi_encode", "ptts_mimi_encode_batch",
-    "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_scheduler_stats_ex", "ptts_q8_linear", "ptts_bf16_linear",
+    "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_scheduler_stats_ex", "ptts_q8_linear", "ptts_q8_linear_q", "ptts_bf16_linear",
     "ptts_tokenizer_new", "ptts_tokenizer_free", "ptts_tokenizer_vocab", "ptts_tokenizer_encode",
     "ptts_audio_load_wav", "ptts_audio_save_wav", "ptts_audio_resample", "ptts_audio_normalize",
     "ptts_onnx_open", "ptts_onnx_close", "ptts_onnx_tensor_count", "ptts_onnx_tensor_info", "ptts_onnx_find",
@@ -120,6 +120,7 @@ def load() -> C.CDLL:
     L.ptts_scheduler_stats.restype = ci; L.ptts_scheduler_stats.argtypes = [vp, C.POINTER(C.c_long)]
     L.ptts_scheduler_stats_ex.restype = ci; L.ptts_scheduler_stats_ex.argtypes = [vp, C.POINTER(C.c_long)]
     L.ptts_q8_linear.restype = ci; L.ptts_q8_linear.argtypes = [vp, f32p, ci, ci, f32p, ci, f32p]
+    L.ptts_q8_linear_q.restype = ci; L.ptts_q8_linear_q.argtypes = [vp, f32p, ci, ci, vp, f32p, ci, f32p]
     L.ptts_bf16_linear.restype = ci
     L.ptts_bf16_linear.argtypes = [vp, f32p, ci, ci, f32p, ci, vp, vp, vp, ci, ci, f32p]
     L.ptts_weight_bytes.restype = ci; L.ptts_weight_bytes.argtypes = [vp, C.POINTER(C.c_ulonglong)]
@@ -451,6 +452,15 @@ class Engine:
         W = np.ascontiguousarray(W, np.float32)
         out = np.empty((A.shape[0], W.shape[0]), np.float32)
         _check(self.L.ptts_q8_linear(self.h, A, A.shape[0], A.shape[1], W, W.shape[0], out), "q8_linear")
+        return out
+
+    def q8_linear_q(self, A, q, scale) -> np.ndarray:
+        """A . (q * scale)^T on the int8 kernel with the matrix given as int8 values [N][K] and per-row scales."""
+        A = np.ascontiguousarray(A, np.float32)
+        q = np.ascontiguousarray(q, np.int8)
+        scale = np.ascontiguousarray(scale, np.float32)
+        out = np.empty((A.shape[0], q.shape[0]), np.float32)
+        _check(self.L.ptts_q8_linear_q(self.h, A, A.shape[0], A.shape[1], q.ctypes.data_as(C.c_void_p), scale, q.shape[0], out), "q8_linear_q")
         return out
 
     def bf16_linear(self, A, W, bias=None, colscale=None, R=None, act=0, split_a=False, a_bf16=False, c_bf16=False) -> np.ndarray:

@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import dataclasses
 import struct
-from typing import Dict, List, Tuple
+from typing import Optional, Dict, List, Tuple
 
 import numpy as np
 
@@ -235,31 +235,50 @@ def synth_weights(s: Spec, seed: int = 1234, eos_bias: float = -20.0,
     return out
 
 
-def write_pack(path: str, s: Spec, weights: Dict[str, np.ndarray]) -> None:
-    table = tensor_table(s)
+def write_pack(path: str, s: Spec, weights: Dict[str, np.ndarray], q8: Optional[Dict[str, Tuple[np.ndarray, np.ndarray]]] = None) -> None:
+    """q8 (optional): name -> (int8 values [N][K], f32 scale per output row [N]) of matrices that exist in int8 form at the
+    source (the `_int8` graphs the reference loads, src/pocket_tts.cpp:90-96).  They are stored beside the f32 tensor as
+    `<name>.q8` (element type 1 = int8) and `<name>.q8s`; the int8 engine multiplies with exactly these values instead of
+    quantising the f32 tensor again."""
+    table = [(name, shape, 0) for name, shape, _ in tensor_table(s)]
+    arrays = {}
+    for name, shape, _ in table:
+        a = weights[name]
+        if tuple(a.shape) != tuple(shape) or a.dtype != np.float32:
+            raise ValueError(f"{name}: expected f32 {shape}, got {a.dtype} {a.shape}")
+        arrays[name] = a
+    for name, (q, sc) in sorted((q8 or {}).items()):
+        if name not in arrays or arrays[name].ndim != 2:
+            raise ValueError(f"{name}: int8 form given for a tensor that is not a matrix of the pack")
+        q = np.ascontiguousarray(q)
+        sc = np.ascontiguousarray(sc, np.float32)
+        if q.dtype != np.int8 or q.shape != arrays[name].shape or sc.shape != (q.shape[0],):
+            raise ValueError(f"{name}: int8 form must be int8 {arrays[name].shape} with {q.shape[0]} f32 scales")
+        table.append((name + ".q8", q.shape, 1))
+        arrays[name + ".q8"] = q
+        table.append((name + ".q8s", sc.shape, 0))
+        arrays[name + ".q8s"] = sc
     n = len(table)
     ints = [int(getattr(s, f)) for f in SPEC_INT_FIELDS] + [0] * (64 - len(SPEC_INT_FIELDS))
     flts = [float(getattr(s, f)) for f in SPEC_FLOAT_FIELDS] + [0.0] * (16 - len(SPEC_FLOAT_FIELDS))
     off = HEADER_SIZE + n * ENTRY_SIZE
     entries = []
-    for name, shape, _ in table:
-        a = weights[name]
-        if tuple(a.shape) != tuple(shape) or a.dtype != np.float32:
-            raise ValueError(f"{name}: expected f32 {shape}, got {a.dtype} {a.shape}")
+    for name, shape, dt in table:
+        a = arrays[name]
         off = (off + 255) & ~255
         shp = list(shape) + [1] * (4 - len(shape))
-        entries.append((name, len(shape), shp, off, a.nbytes))
+        entries.append((name, dt, len(shape), shp, off, a.nbytes))
         off += a.nbytes
     with open(path, "wb") as f:
         f.write(MAGIC)
         f.write(struct.pack("<II", VERSION, n))
         f.write(struct.pack("<64i", *ints))
         f.write(struct.pack("<16f", *flts))
-        for name, ndim, shp, o, nb in entries:
-            f.write(struct.pack(ENTRY_FMT, name.encode(), 0, ndim, *shp, o, nb))
-        for (name, _, _), (_, _, _, o, nb) in zip(table, entries):
+        for name, dt, ndim, shp, o, nb in entries:
+            f.write(struct.pack(ENTRY_FMT, name.encode(), dt, ndim, *shp, o, nb))
+        for name, dt, ndim, shp, o, nb in entries:
             f.seek(o)
-            f.write(weights[name].tobytes())
+            f.write(arrays[name].tobytes())
 
 
 def read_pack(path: str) -> Tuple[Spec, Dict[str, np.ndarray]]:
@@ -282,8 +301,28 @@ def read_pack(path: str) -> Tuple[Spec, Dict[str, np.ndarray]]:
         ndim = e[2]
         shape = tuple(e[3:3 + ndim])
         o, nb = e[7], e[8]
+        if e[1] == 1 or name.endswith(".q8s"):
+            continue                      # int8 forms: read_pack_q8
         w[name] = np.frombuffer(raw, dtype=np.float32, count=nb // 4, offset=o).reshape(shape).copy()
     return s, w
+
+
+def read_pack_q8(path: str) -> Dict[str, Tuple[np.ndarray, np.ndarray]]:
+    """The int8 forms a pack carries: name -> (int8 [N][K], f32 scale [N])."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    n = struct.unpack_from("<II", raw, 8)[1]
+    q, sc = {}, {}
+    for i in range(n):
+        e = struct.unpack_from(ENTRY_FMT, raw, HEADER_SIZE + i * ENTRY_SIZE)
+        name = e[0].rstrip(b"\0").decode()
+        shape = tuple(e[3:3 + e[2]])
+        o, nb = e[7], e[8]
+        if e[1] == 1 and name.endswith(".q8"):
+            q[name[:-3]] = np.frombuffer(raw, dtype=np.int8, count=nb, offset=o).reshape(shape).copy()
+        elif name.endswith(".q8s"):
+            sc[name[:-4]] = np.frombuffer(raw, dtype=np.float32, count=nb // 4, offset=o).copy()
+    return {k: (q[k], sc[k]) for k in q if k in sc}
 
 
 def make_pack(path: str, spec: Spec, seed: int = 1234, eos_bias: float = -20.0,

@@ -20,9 +20,26 @@ Per entry: `transpose` swaps a 2-D matrix to [out][in]; `conv` turns a Conv1d we
 (q - zero_point) * scale with `axis` (default: the axis the scales fit); `rows: [a, b]` keeps rows a..b-1;
 `reshape` forces the final shape.
 
+Matrices that the int8 engine multiplies in int8 (`ptts_pack.is_int8_weight`: the LM layers' qkv / out / ff1 / ff2 and the
+flow blocks' fc1 / fc2) and that arrive as a `_quantized` / `_scale` / `_zero_point` triplet are carried into the pack as
+they are — int8 values (q - zero_point) and one scale per output row, next to the dequantised f32 tensor — whenever the
+triplet allows it: scale per tensor or per output channel, q - zero_point within int8.  The int8 engine then multiplies
+with the source's own integers; other triplets are only dequantised.
+
 `--list` prints every tensor (name, type, shape) and, for MatMul / Gemm / Conv / ConvTranspose / Gather nodes, which
 initializer each consumes: the raw material for writing the map.  `--auto` maps by equal names (files whose
 initializers are already named like pack tensors), transposing 2-D tensors whose shape is the reverse of the pack's.
+`--guess OUT.json` writes a first draft of the map for files whose initializers carry exporter names: per graph file it
+walks the nodes in graph order and gives every pack tensor of that graph (in the pack's own layer order) the first unused
+initializer whose shape fits (as stored, transposed, or as a Conv1d weight); what it cannot place is listed under
+"unresolved".  The draft is for a person to review against `--list`: shapes repeat from layer to layer, and only the
+order of the graph tells them apart.
+
+What the reference itself pins are the names of the graphs' inputs and outputs, not of their weights:
+mimi_encoder `audio` -> `latents` (src/pocket_tts.cpp:266-267); text_conditioner `token_ids` -> `embeddings` (:305-306);
+flow_lm_main `sequence`, `text_embeddings`, `state_<i>` -> conditioning, EOS logit, `out_state_<i>` (:340-345, :400-402);
+flow_lm_flow `c`, `s`, `t`, `x` -> `flow_dir` (:439-440); mimi_decoder `latent`, `state_<i>` -> audio, `out_state_<i>`
+(:483, :534-536).  GRAPH_IO below holds them.
 """
 import argparse
 import json
@@ -36,6 +53,29 @@ sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pyhost"))
 
 import ptts_onnx  # noqa: E402
 import ptts_pack as pp  # noqa: E402
+
+GRAPH_IO = {
+    "mimi_encoder": (["audio"], ["latents"]),
+    "text_conditioner": (["token_ids"], ["embeddings"]),
+    "flow_lm_main": (["sequence", "text_embeddings", "state_<i>"], ["<conditioning>", "<eos logit>", "out_state_<i>"]),
+    "flow_lm_flow": (["c", "s", "t", "x"], ["flow_dir"]),
+    "mimi_decoder": (["latent", "state_<i>"], ["<audio>", "out_state_<i>"]),
+}
+
+
+def graph_file(name, int8=False):
+    """The file of the reference's model directory that holds pack tensor `name` (src/pocket_tts.cpp:90-96)."""
+    suffix = "_int8" if int8 else ""
+    if name.startswith("enc."):
+        return "mimi_encoder.onnx"
+    if name.startswith("text."):
+        return "text_conditioner.onnx"
+    if name.startswith("lm."):
+        return f"flow_lm_main{suffix}.onnx"
+    if name.startswith("flow."):
+        return f"flow_lm_flow{suffix}.onnx"
+    return f"mimi_decoder{suffix}.onnx"
+
 
 REFERENCE_FILES = ["mimi_encoder.onnx", "text_conditioner.onnx", "flow_lm_main.onnx", "flow_lm_flow.onnx", "mimi_decoder.onnx",
                    "flow_lm_main_int8.onnx", "flow_lm_flow_int8.onnx", "mimi_decoder_int8.onnx"]
@@ -59,6 +99,42 @@ def list_models(models_dir):
                 fed = [i for i in ins if i in ow.info]
                 if fed:
                     print(f"   node {op} -> {outs[0] if outs else '?'} uses {fed}")
+
+
+def fetch_q8(files, entry, want_shape):
+    """The int8 form (q [N][K] int8, scale [N] f32) of a map entry whose source is a quantised triplet, or None."""
+    if "concat" in entry or "rows" in entry or "reshape" in entry or entry.get("conv") or want_shape is None or len(want_shape) != 2:
+        return None
+    ow = files.get(entry["file"])
+    name = entry["tensor"]
+    if ow is None or not ow.has_quantized(name) or entry.get("dequantize") is False:
+        return None
+    q = ow.read(name + "_quantized")
+    sc = ow.read(name + "_scale").reshape(-1)
+    zp = ow.read(name + "_zero_point").reshape(-1) if name + "_zero_point" in ow.info else np.zeros(1, np.float32)
+    if q.ndim != 2:
+        return None
+    if entry.get("transpose"):
+        q = q.T                      # now [out][in]; a per-column scale of the stored matrix is per output row here
+        out_axis_src = 1
+    else:
+        out_axis_src = 0
+    axis = int(entry.get("axis", -1))
+    N = q.shape[0]
+    if sc.size == 1:
+        sc = np.full(N, sc[0], np.float32)
+    elif sc.size == N and (axis in (-1, out_axis_src)):
+        pass
+    else:
+        return None                  # scales along the input axis: no per-row form
+    if zp.size == 1:
+        zp = np.full(N, zp[0], np.float32)
+    elif zp.size != N:
+        return None
+    qi = np.rint(q - zp[:, None])
+    if tuple(qi.shape) != tuple(want_shape) or qi.min() < -128 or qi.max() > 127:
+        return None
+    return np.ascontiguousarray(qi.astype(np.int8)), np.ascontiguousarray(sc, np.float32)
 
 
 def fetch(files, entry, want_shape):
@@ -107,6 +183,59 @@ def auto_map(files, table):
     return tensors
 
 
+def guess_map(models_dir, spec, int8=False):
+    """First draft of a name map by shape and graph order; returns (tensors, unresolved)."""
+    files = open_all(models_dir)
+    order = {}
+    for fn, ow in files.items():
+        seq, seen = [], set()
+
+        def add(nm):
+            base = nm[:-len("_quantized")] if nm.endswith("_quantized") else nm
+            if base in seen or nm.endswith(("_scale", "_zero_point")):
+                return
+            key = base + "_quantized" if base + "_quantized" in ow.info else base
+            if key in ow.info:
+                seen.add(base)
+                seq.append((base, tuple(ow.info[key][2])))
+        for _, ins, _ in ow.nodes():
+            for i in ins:
+                add(i)
+        for nm in ow.info:
+            add(nm)
+        order[fn] = seq
+    tensors, unresolved, used = {}, [], {fn: set() for fn in files}
+    for name, shape, _ in pp.tensor_table(spec):
+        fn = graph_file(name, int8)
+        if fn not in files and int8:
+            fn = graph_file(name, False)
+        want = tuple(shape)
+        squeeze = lambda t: tuple(d for d in t if d != 1)
+        hit = None
+        for base, have in order.get(fn, []):
+            if base in used[fn]:
+                continue
+            ent = {"file": fn, "tensor": base, "guessed": True}
+            if have == want or squeeze(have) == squeeze(want):
+                hit = ent
+            elif len(want) == 2 and len(have) == 2 and have == want[::-1]:
+                ent["transpose"] = True
+                hit = ent
+            elif len(want) == 2 and len(have) == 3 and have[0] == want[0] and have[1] * have[2] == want[1]:
+                ent["conv"] = True
+                hit = ent
+            if hit:
+                used[fn].add(base)
+                break
+        if hit:
+            tensors[name] = hit
+        else:
+            unresolved.append({"pack_tensor": name, "shape": list(want), "file": fn})
+    for ow in files.values():
+        ow.close()
+    return tensors, unresolved
+
+
 def convert(models_dir, out_path, map_path=None, auto=False, spec_over=None):
     m = json.load(open(map_path)) if map_path else {}
     spec_kw = dict(m.get("spec", {}))
@@ -120,9 +249,16 @@ def convert(models_dir, out_path, map_path=None, auto=False, spec_over=None):
     if missing:
         raise SystemExit(f"{len(missing)} pack tensors have no source, e.g. {missing[:8]}; add them to the map (see --list)")
     weights = {name: fetch(files, tensors[name], shape) for name, shape, _ in table}
-    pp.write_pack(out_path, spec, weights)
+    q8 = {}
+    for name, shape, _ in table:
+        if pp.is_int8_weight(name, spec.flow_dim):
+            got = fetch_q8(files, tensors[name], shape)
+            if got is not None:
+                q8[name] = got
+    pp.write_pack(out_path, spec, weights, q8=q8)
     for ow in files.values():
         ow.close()
+    convert.last_q8 = sorted(q8)
     return spec, weights
 
 
@@ -133,15 +269,25 @@ def main():
     ap.add_argument("--map")
     ap.add_argument("--auto", action="store_true")
     ap.add_argument("--out", default=None, help="default: <models_dir>/pocket_tts.ptts")
+    ap.add_argument("--guess", metavar="OUT.json", help="write a draft map by shape and graph order (review it against --list)")
+    ap.add_argument("--int8", action="store_true", help="--guess: take the LM, flow and decoder tensors from the _int8 graphs")
     args = ap.parse_args()
     if args.list:
         list_models(args.models_dir)
+        return
+    if args.guess:
+        spec_kw = json.load(open(args.map)).get("spec", {}) if args.map else {}
+        spec = pp.Spec(**spec_kw)
+        tensors, unresolved = guess_map(args.models_dir, spec, args.int8)
+        full_kw = {f: getattr(spec, f) for f in pp.SPEC_INT_FIELDS + pp.SPEC_FLOAT_FIELDS}
+        json.dump({"spec": full_kw, "tensors": tensors, "unresolved": unresolved, "graph_io": GRAPH_IO}, open(args.guess, "w"), indent=1)
+        print(f"wrote {args.guess}: {len(tensors)} tensors placed, {len(unresolved)} unresolved")
         return
     if not args.map and not args.auto:
         ap.error("give --map FILE and/or --auto (or --list to see what the files hold)")
     out = args.out or os.path.join(args.models_dir, "pocket_tts.ptts")
     spec, w = convert(args.models_dir, out, args.map, args.auto)
-    print(f"wrote {out}: {len(w)} tensors, {sum(a.nbytes for a in w.values()) / 1e6:.1f} MB")
+    print(f"wrote {out}: {len(w)} tensors, {sum(a.nbytes for a in w.values()) / 1e6:.1f} MB; {len(convert.last_q8)} matrices carried in int8")
 
 
 if __name__ == "__main__":

@@ -163,6 +163,15 @@ def test_converter_round_trip(tmp_path, packs, ponnx):
             assert np.all(np.abs(w2[name] - w[name]).max(1) <= s_max * 0.51 + 1e-7), name
         else:
             np.testing.assert_array_equal(w2[name], w[name], err_msg=name)
+    # the quantised matrices travel as int8: the integers and per-row scales of the source, not a second quantisation
+    q8 = pp.read_pack_q8(out)
+    carried = [n for n, _, _ in table if n.startswith("lm.l0.") and n.endswith(".w") and w[n].ndim == 2]
+    assert sorted(q8) == sorted(carried) and carried
+    for name in carried:
+        q, sc, _ = ow.quantize_per_axis(np.ascontiguousarray(w[name].T), 1)
+        np.testing.assert_array_equal(q8[name][0], q.T, err_msg=name)
+        np.testing.assert_array_equal(q8[name][1], sc, err_msg=name)
+        np.testing.assert_array_equal(w2[name], q8[name][0].astype(np.float32) * q8[name][1][:, None], err_msg=name)
     # a map that misses tensors is refused with their names
     (tmp_path / "map2.json").write_text(json.dumps({"spec": spec_kw, "tensors": {k: v for k, v in mapping.items() if not k.startswith("enc.")}}))
     with pytest.raises(SystemExit, match="no source"):
@@ -191,3 +200,40 @@ def test_converter_auto_map(tmp_path, packs, ponnx):
     _, w2 = pp.read_pack(out)
     for name in w:
         np.testing.assert_array_equal(w2[name], w[name], err_msg=name)
+
+
+def test_guess_map_by_shape_and_graph_order(tmp_path, packs, ponnx):
+    """Exporter-style files: opaque initializer names, one node per tensor in the model's own layer order, matrices stored
+    [in][out], conv weights [Cout][Cin][k].  The draft map places every tensor, and the pack built from it is the model."""
+    import onnx_to_ptts
+    import ptts_pack as pp
+    path, spec, w = packs["tiny"]
+    mdir = tmp_path / "onnx"
+    mdir.mkdir()
+    per_file, nodes = {}, {}
+    for k, (name, shape, _) in enumerate(pp.tensor_table(spec)):
+        a = w[name]
+        fn = onnx_to_ptts.graph_file(name)
+        tname = f"onnx::T_{7000 + 3 * k}"
+        if a.ndim == 2 and name.endswith(".w") and name.startswith(("lm.", "flow.")) and a.shape[0] != a.shape[1]:
+            a = np.ascontiguousarray(a.T)
+            op = "MatMul"
+        elif name in ("dec.conv0.w", "enc.conv0.w"):
+            a = np.ascontiguousarray(a.reshape(a.shape[0], spec.kernel, -1).transpose(0, 2, 1))
+            op = "Conv"
+        else:
+            op = "MatMul" if a.ndim == 2 else "Add"
+        per_file.setdefault(fn, []).append(ow.tensor(tname, a))
+        nodes.setdefault(fn, []).append(ow.node(op, [f"act_{k}", tname], [f"act_{k + 1}"]))
+    for fn in per_file:
+        (mdir / fn).write_bytes(ow.model(per_file[fn][::-1], nodes[fn]))     # initializers stored in another order than the nodes
+    spec_kw = {f: getattr(spec, f) for f in pp.SPEC_INT_FIELDS + pp.SPEC_FLOAT_FIELDS}
+    tensors, unresolved = onnx_to_ptts.guess_map(str(mdir), pp.Spec(**spec_kw))
+    assert not unresolved and len(tensors) == len(pp.tensor_table(spec))
+    (tmp_path / "draft.json").write_text(json.dumps({"spec": spec_kw, "tensors": tensors}))
+    out = str(tmp_path / "guessed.ptts")
+    onnx_to_ptts.convert(str(mdir), out, str(tmp_path / "draft.json"))
+    _, w2 = pp.read_pack(out)
+    for name in w:
+        np.testing.assert_array_equal(w2[name], w[name], err_msg=name)
+    assert set(onnx_to_ptts.GRAPH_IO) == {"mimi_encoder", "text_conditioner", "flow_lm_main", "flow_lm_flow", "mimi_decoder"}
