@@ -19,7 +19,7 @@
 #  define POCKET_TTS_API __attribute__((visibility("default")))
 #endif
 
-namespace ptts { class Engine; }
+namespace ptts { class Engine; struct Utterance; struct UtteranceResult; }
 
 namespace pocket_tts {
 
@@ -85,6 +85,13 @@ public:
     std::vector<float> encodeVoiceFromSamples(const float* samples, int count, int sampleRate);
     std::vector<int64_t> tokenize(const std::string& text) const;
     ptts::Engine& engine();
+    // Additive: with POCKET_TTS_DEVICES=0,1,... in the environment the object holds one engine per listed GPU (the
+    // reference has one CPU session set per object, src/pocket_tts.cpp:80-113).  pickEngine() is the engine with the fewest
+    // utterances pending; generateQueue() deals a batch out over all of them.
+    ptts::Engine& pickEngine();
+    int engineCount() const;
+    ptts::Engine& engineAt(int i);
+    void generateQueue(const std::vector<ptts::Utterance>& utts, std::vector<ptts::UtteranceResult>& out, bool wantLatents);
     const PocketTTSConfig& config() const;
 
 private:

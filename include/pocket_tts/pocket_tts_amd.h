@@ -173,6 +173,10 @@ POCKET_TTS_API int ptts_scheduler_stats(PocketTTSHandle handle, long* stats);
 /* ... and stats[3] = frame steps launched, [4] = sum of the launch width over them, [5] = frames delivered to callers,
  * [6] = decoder chunk calls, [7] = prefill passes (8 entries). */
 POCKET_TTS_API int ptts_scheduler_stats_ex(PocketTTSHandle handle, long* stats);
+/* Engines behind the handle: one per GPU listed in the environment variable POCKET_TTS_DEVICES (e.g. "0,1,2,3") when the
+ * handle was created, else one.  served[i] (i < cap, may be NULL) receives the utterances engine i has served.  Single
+ * utterances and streams go to the engine with the fewest utterances pending, queued batches are dealt out over all. */
+POCKET_TTS_API int ptts_engine_count(PocketTTSHandle handle, long* served, int cap);
 POCKET_TTS_API int ptts_phase_times(PocketTTSHandle handle, double* times_ms, long* calls);
 /* bytes[0..3] = GEMM weight bytes (compute precision) of the LM, the flow head, the decoder, the encoder */
 POCKET_TTS_API int ptts_weight_bytes(PocketTTSHandle handle, unsigned long long* bytes);

@@ -240,7 +240,7 @@ POCKET_TTS_API int pocket_tts_generate_batch(PocketTTSHandle handle, int n, cons
             utts[i].voice_frames = static_cast<int>(v->shape[1]);
         }
         std::vector<ptts::UtteranceResult> res;
-        tts->engine().generate_queue(utts, res, false);   // slot table: any n, finished slots are refilled from the rest
+        tts->generateQueue(utts, res, false);   // slot table(s): any n, finished slots are refilled from the rest
         for (int i = 0; i < n; ++i) fill_result(&results[i], res[i].audio, tts->engine().spec().sample_rate);
         return 0;
     });
@@ -262,10 +262,10 @@ static int generate_ids_impl(PocketTTSHandle handle, int n, const long long* con
         }
         std::vector<ptts::UtteranceResult> res;
         if (queued) {
-            tts->engine().generate_queue(utts, res, want);
+            tts->generateQueue(utts, res, want);
         } else if (n == 1) {   // single utterances share the slot table with concurrent callers, like pocket_tts_generate
             res.resize(1);
-            tts->engine().generate_one(utts[0], res[0], want);
+            tts->pickEngine().generate_one(utts[0], res[0], want);
         } else {
             tts->engine().generate(utts, res, want);
         }
@@ -354,7 +354,7 @@ POCKET_TTS_API int pocket_tts_streaming_ids(PocketTTSHandle handle, const long l
         u.voice = voice;
         u.voice_frames = voice_frames;
         u.noise = noise;
-        return tts_of(handle)->engine().generate_streaming(
+        return tts_of(handle)->pickEngine().generate_streaming(
             u, chunk_size_frames > 0 ? chunk_size_frames : 5,
             [callback, user_data](const float* s, int n, bool fin) { callback(s, n, fin ? 1 : 0, user_data); }, nullptr, false, nullptr,
             nullptr);
@@ -576,10 +576,24 @@ POCKET_TTS_API int ptts_scheduler_stats(PocketTTSHandle handle, long* stats) {
 POCKET_TTS_API int ptts_scheduler_stats_ex(PocketTTSHandle handle, long* stats) {
     if (!handle || !stats) { set_error("Invalid parameters"); return -1; }
     return guarded("scheduler_stats: ", [&] {
-        auto st = tts_of(handle)->engine().scheduler_stats();
-        stats[0] = st.batches; stats[1] = st.utterances; stats[2] = st.largest; stats[3] = st.frame_steps; stats[4] = st.slot_steps;
-        stats[5] = st.frames; stats[6] = st.decode_calls; stats[7] = st.admissions;
+        for (int k = 0; k < 8; ++k) stats[k] = 0;
+        auto* tts = tts_of(handle);
+        for (int e = 0; e < tts->engineCount(); ++e) {   // summed over the handle's engines (largest: the maximum)
+            auto st = tts->engineAt(e).scheduler_stats();
+            stats[0] += st.batches; stats[1] += st.utterances; stats[2] = std::max(stats[2], st.largest); stats[3] += st.frame_steps;
+            stats[4] += st.slot_steps; stats[5] += st.frames; stats[6] += st.decode_calls; stats[7] += st.admissions;
+        }
         return 0;
+    });
+}
+
+/* Engines behind the handle (POCKET_TTS_DEVICES) and, per engine, the utterances it has served: served[i] for i < cap. */
+POCKET_TTS_API int ptts_engine_count(PocketTTSHandle handle, long* served, int cap) {
+    if (!handle) { set_error("Invalid parameters"); return -1; }
+    return guarded("engine_count: ", [&] {
+        auto* tts = tts_of(handle);
+        for (int e = 0; e < tts->engineCount() && served && e < cap; ++e) served[e] = tts->engineAt(e).scheduler_stats().utterances;
+        return tts->engineCount();
     });
 }
 

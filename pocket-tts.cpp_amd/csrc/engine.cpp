@@ -532,6 +532,9 @@ void Batch::reset(hipStream_t s) {
 
 namespace {
 float silu_h(float v) { return v / (1.0f + std::exp(-v)); }
+// One persistent flow head can be resident per GPU (192 of its 256 CUs at one workgroup each).  Of the engines a process
+// creates on a device the first holds that slot until it is destroyed; the others run the head as a launch chain.
+std::atomic<int> g_ring_owner[64];
 }  // namespace
 
 Engine::Engine(const EngineOptions& opt) : opt_(opt) {
@@ -542,6 +545,10 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
     if (opt_.device < 0 || opt_.device >= ndev) throw std::runtime_error("engine: device ordinal out of range");
     PTTS_HIP(hipSetDevice(opt_.device));
     PTTS_TRACE("ctor: device set");
+    {
+        int expect = 0;
+        owns_ring_ = g_ring_owner[opt_.device & 63].compare_exchange_strong(expect, 1);
+    }
     // Spatial split of the compute units: the decoder stream is confined to k of every 8 blocks of 8 CUs
     // (POCKET_TTS_DECODER_CU_EIGHTHS, default 4, 0 = no mask), so its wide kernels always leave CUs free for the
     // frame loop's small dependent launches.  Measured at B = 64 on MI355X: no mask 3350 RTFx, k = 4 3620, k = 3 3540,
@@ -679,6 +686,7 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
 
 Engine::~Engine() {
     PTTS_TRACE("dtor: begin");
+    struct Release { bool own; int dev; ~Release() { if (own) g_ring_owner[dev & 63].store(0); } } release{owns_ring_, opt_.device};
     stop_worker();
     PTTS_TRACE("dtor: worker joined");
     (void)hipSetDevice(opt_.device);
@@ -1101,7 +1109,7 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
     FlowHeadArgs probe;
     probe.C = C; probe.L = s.latent; probe.blocks = s.flow_blocks; probe.steps = N; probe.B = B; probe.wtype = model_->flow_wtype;
     probe.block_wtype = model_->flow_block_wtype; probe.ring_ctl = fs.ctl; probe.ring_wg_budget = 224 / std::max(lanes_, 1);
-    const bool ring = fs.ctl && flow_ring_supported(probe);
+    const bool ring = owns_ring_ && fs.ctl && flow_ring_supported(probe);
     const int cw = static_cast<int>(flow_ring_counter_word());
     launch_flow_mod_input(flow_te_.f(), fs.cemb, cs, hd_.flow_cond_b, fs.ymod, N, B, C, st, frame ? &pub : nullptr, ring ? fs.ctl + cw : nullptr,
                           ring ? static_cast<int>(flow_ring_ctl_bytes(B, s.flow_blocks) / 4) - cw : 0);

@@ -176,6 +176,8 @@ public:
         long admissions = 0;    // prefill passes
     };
     SchedulerStats scheduler_stats();
+    // utterances handed to this engine's slot table and not yet returned (what a dispatcher over several engines balances)
+    int pending() const { return pending_.load(); }
     // The same in three parts, so a benchmark can time the device-resident middle on its own:
     //   stage (host -> HBM), run_staged (prefill + frame loop + decode, audio left in HBM), fetch_staged (HBM -> host).
     // Hold call_mutex() across the three when other threads may use the engine.
@@ -292,6 +294,8 @@ private:
     };
     EncSlot enc_slot_[2];
     std::mutex enc_mu_;
+    std::atomic<int> pending_{0};
+    bool owns_ring_ = false;   // this engine holds its GPU's one persistent flow-head slot (see flow_ring.hip)
     std::map<std::pair<int, int>, std::unique_ptr<Batch>> batch_pool_;   // (rows, lane)
     std::list<std::pair<int, int>> batch_lru_;                           // keys of batch_pool_, most recently used first
     static constexpr size_t kMaxPooled = 8;                              // batch sizes kept warm per engine

@@ -3,11 +3,14 @@
 // Interface contract: /root/reference/include/pocket_tts/pocket_tts.hpp:78-163; the behaviour of each
 // method follows /root/reference/src/pocket_tts.cpp (encodeVoice :241-297, generate :548-657,
 // generateWithEmbeddings :676-684, generateStreaming :686-979, cancelStreaming :981-983).
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <iostream>
 #include <map>
 #include <mutex>
+#include <sstream>
+#include <thread>
 
 #include "engine.h"
 #include "pocket_tts/audio_utils.hpp"
@@ -19,6 +22,10 @@ namespace pocket_tts {
 struct PocketTTS::Impl {
     PocketTTSConfig config;
     std::unique_ptr<ptts::Engine> engine;
+    // POCKET_TTS_DEVICES=0,1,...: one more engine (weights, slot table, worker thread) per further device behind this one
+    // handle; single utterances and streams go to the engine with the fewest utterances pending, queued batches are dealt
+    // out over all of them.  `engine` is the first listed device and serves everything else (operators, voice encoding).
+    std::vector<std::unique_ptr<ptts::Engine>> more;
     std::unique_ptr<Tokenizer> tokenizer;
     std::mutex cache_mu;
     std::map<std::string, std::vector<float>> voice_cache;  // keyed by path, like the reference (:75, :243-246)
@@ -40,11 +47,32 @@ struct PocketTTS::Impl {
         o.seed = cfg.seed;
         o.has_seed = cfg.hasSeed;
         if (cfg.verbose) std::cout << "Loading weight pack " << o.pack_path << " (precision: " << cfg.precision << ")..." << std::endl;
+        std::vector<int> devices;
+        if (const char* e = std::getenv("POCKET_TTS_DEVICES")) {
+            std::stringstream ss(e);
+            for (std::string tok; std::getline(ss, tok, ',');)
+                if (!tok.empty()) devices.push_back(std::stoi(tok));
+        }
+        if (!devices.empty()) o.device = devices[0];
         engine = std::make_unique<ptts::Engine>(o);
+        for (size_t i = 1; i < devices.size(); ++i) {
+            ptts::EngineOptions oi = o;
+            oi.device = devices[i];
+            if (oi.has_seed) oi.seed += i;
+            more.push_back(std::make_unique<ptts::Engine>(oi));
+        }
+        if (cfg.verbose && !more.empty()) std::cout << "Engines on " << devices.size() << " devices." << std::endl;
         if (cfg.loadTokenizer) {
             tokenizer = std::make_unique<Tokenizer>(cfg.tokenizerPath);
             if (cfg.verbose) std::cout << "Tokenizer loaded (vocab size: " << tokenizer->vocabSize() << ")." << std::endl;
         }
+    }
+
+    ptts::Engine& least_loaded() {
+        ptts::Engine* best = engine.get();
+        for (auto& e : more)
+            if (e->pending() < best->pending()) best = e.get();
+        return *best;
     }
 
     std::vector<int64_t> tokenize(const std::string& text) const {
@@ -89,6 +117,35 @@ PocketTTS::PocketTTS(PocketTTS&&) noexcept = default;
 PocketTTS& PocketTTS::operator=(PocketTTS&&) noexcept = default;
 
 ptts::Engine& PocketTTS::engine() { return *impl_->engine; }
+ptts::Engine& PocketTTS::pickEngine() { return impl_->least_loaded(); }
+int PocketTTS::engineCount() const { return 1 + static_cast<int>(impl_->more.size()); }
+ptts::Engine& PocketTTS::engineAt(int i) { return i <= 0 ? *impl_->engine : *impl_->more.at(static_cast<size_t>(i - 1)); }
+
+// Queued utterances over every engine of the handle: dealt out in turn starting with the least loaded engine, each engine's
+// share runs through its own slot table, all of them at once.
+void PocketTTS::generateQueue(const std::vector<ptts::Utterance>& utts, std::vector<ptts::UtteranceResult>& out, bool wantLatents) {
+    if (impl_->more.empty()) { impl_->engine->generate_queue(utts, out, wantLatents); return; }
+    std::vector<ptts::Engine*> engines{impl_->engine.get()};
+    for (auto& e : impl_->more) engines.push_back(e.get());
+    std::stable_sort(engines.begin(), engines.end(), [](ptts::Engine* a, ptts::Engine* b) { return a->pending() < b->pending(); });
+    const size_t E = engines.size();
+    std::vector<std::vector<ptts::Utterance>> part(E);
+    std::vector<std::vector<size_t>> index(E);
+    for (size_t i = 0; i < utts.size(); ++i) { part[i % E].push_back(utts[i]); index[i % E].push_back(i); }
+    std::vector<std::vector<ptts::UtteranceResult>> res(E);
+    std::vector<std::exception_ptr> err(E);
+    std::vector<std::thread> th;
+    for (size_t e = 0; e < E; ++e)
+        th.emplace_back([&, e] {
+            try { if (!part[e].empty()) engines[e]->generate_queue(part[e], res[e], wantLatents); }
+            catch (...) { err[e] = std::current_exception(); }
+        });
+    for (auto& t : th) t.join();
+    for (auto& x : err) if (x) std::rethrow_exception(x);
+    out.assign(utts.size(), ptts::UtteranceResult());
+    for (size_t e = 0; e < E; ++e)
+        for (size_t k = 0; k < index[e].size(); ++k) out[index[e][k]] = std::move(res[e][k]);
+}
 const PocketTTSConfig& PocketTTS::config() const { return impl_->config; }
 std::vector<int64_t> PocketTTS::tokenize(const std::string& text) const { return impl_->tokenize(text); }
 
@@ -122,7 +179,7 @@ std::vector<float> PocketTTS::generateWithEmbeddings(const std::string& text, co
     u.voice = voiceEmbeddings.data();
     u.voice_frames = impl_->frames_of(voiceEmbeddings, voiceEmbeddingShape);
     ptts::UtteranceResult res;
-    impl_->engine->generate_one(u, res, false);   // coalesces with concurrent callers
+    impl_->least_loaded().generate_one(u, res, false);   // a slot of that engine's table, beside concurrent callers' utterances
     return std::move(res.audio);
 }
 
@@ -139,7 +196,7 @@ int PocketTTS::generateStreaming(const std::string& text, const std::vector<floa
     std::function<void(int)> progress;
     if (streamConfig.onProgress) progress = [&](int frame) { streamConfig.onProgress(frame, 0); };
     auto t0 = std::chrono::high_resolution_clock::now();
-    int total = impl_->engine->generate_streaming(u, streamConfig.chunkSizeFrames, callback, &impl_->cancel_requested,
+    int total = impl_->least_loaded().generate_streaming(u, streamConfig.chunkSizeFrames, callback, &impl_->cancel_requested,
                                                   streamConfig.enableCancellation, progress, nullptr);
     if (impl_->config.verbose) {
         auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();

@@ -228,7 +228,16 @@ void Engine::submit_all(Request* const* reqs, size_t n) {
     q_cv_.notify_all();
 }
 
+namespace {
+struct PendingGuard {
+    std::atomic<int>& c; int n;
+    PendingGuard(std::atomic<int>& counter, int k) : c(counter), n(k) { c.fetch_add(n); }
+    ~PendingGuard() { c.fetch_sub(n); }
+};
+}  // namespace
+
 void Engine::generate_one(const Utterance& utt, UtteranceResult& out, bool want_latents) {
+    PendingGuard pend(pending_, 1);
     Request r;
     r.utt = utt;
     r.want_latents = want_latents;
@@ -241,6 +250,7 @@ void Engine::generate_one(const Utterance& utt, UtteranceResult& out, bool want_
 }
 
 void Engine::generate_queue(const std::vector<Utterance>& utts, std::vector<UtteranceResult>& out, bool want_latents) {
+    PendingGuard pend(pending_, static_cast<int>(utts.size()));
     out.assign(utts.size(), UtteranceResult());
     std::vector<std::unique_ptr<Request>> reqs;
     std::vector<Request*> ptrs;
@@ -267,6 +277,7 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
     if (!cb) throw std::invalid_argument("Callback must be provided");   // src/pocket_tts.cpp:693-695
     if (std::getenv("POCKET_TTS_INLINE_STREAMING")) return generate_streaming_inline(utt, chunk_frames, cb, cancel_flag, poll_cancel, progress, capture);
     if (chunk_frames <= 0) chunk_frames = 1;
+    PendingGuard pend(pending_, 1);
     Request r;
     UtteranceResult local;
     r.utt = utt;

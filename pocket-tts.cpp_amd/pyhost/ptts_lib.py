@@ -51,7 +51,7 @@ EXT_SYMBOLS = [
     "pocket_tts_stage_ids", "pocket_tts_run_staged", "pocket_tts_fetch_staged",
     "pocket_tts_tokenize", "ptts_text_conditioner", "ptts_state_new", "ptts_state_free", "ptts_state_reset",
     "ptts_lm_prefill", "ptts_lm_step", "ptts_flow_euler", "ptts_flow_euler_noalloc", "ptts_flow_euler_noalloc_capacity", "ptts_mimi_decode", "ptts_mimi_encode", "ptts_mimi_encode_batch",
-    "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_scheduler_stats_ex", "ptts_q8_linear", "ptts_q8_linear_q", "ptts_bf16_linear",
+    "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_scheduler_stats_ex", "ptts_engine_count", "ptts_q8_linear", "ptts_q8_linear_q", "ptts_bf16_linear",
     "ptts_tokenizer_new", "ptts_tokenizer_free", "ptts_tokenizer_vocab", "ptts_tokenizer_encode",
     "ptts_audio_load_wav", "ptts_audio_save_wav", "ptts_audio_resample", "ptts_audio_normalize",
     "ptts_onnx_open", "ptts_onnx_close", "ptts_onnx_tensor_count", "ptts_onnx_tensor_info", "ptts_onnx_find",
@@ -120,6 +120,7 @@ def load() -> C.CDLL:
     L.ptts_scheduler_stats.restype = ci; L.ptts_scheduler_stats.argtypes = [vp, C.POINTER(C.c_long)]
     L.ptts_scheduler_stats_ex.restype = ci; L.ptts_scheduler_stats_ex.argtypes = [vp, C.POINTER(C.c_long)]
     L.ptts_q8_linear.restype = ci; L.ptts_q8_linear.argtypes = [vp, f32p, ci, ci, f32p, ci, f32p]
+    L.ptts_engine_count.restype = ci; L.ptts_engine_count.argtypes = [vp, C.POINTER(C.c_long), ci]
     L.ptts_q8_linear_q.restype = ci; L.ptts_q8_linear_q.argtypes = [vp, f32p, ci, ci, vp, f32p, ci, f32p]
     L.ptts_bf16_linear.restype = ci
     L.ptts_bf16_linear.argtypes = [vp, f32p, ci, ci, f32p, ci, vp, vp, vp, ci, ci, f32p]
@@ -479,6 +480,12 @@ class Engine:
         _check(self.L.ptts_scheduler_stats_ex(self.h, st), "scheduler_stats")
         return dict(batches=st[0], utterances=st[1], largest=st[2], frame_steps=st[3], slot_steps=st[4], frames=st[5],
                     decode_calls=st[6], admissions=st[7])
+
+    def engine_served(self) -> List[int]:
+        """Utterances served by each engine behind the handle (one engine per device of POCKET_TTS_DEVICES)."""
+        buf = (C.c_long * 64)()
+        n = _check(self.L.ptts_engine_count(self.h, buf, 64), "engine_count")
+        return [int(buf[i]) for i in range(n)]
 
     def weight_bytes(self):
         b = (C.c_ulonglong * 4)()

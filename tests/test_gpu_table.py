@@ -197,3 +197,41 @@ def test_int8_512_ragged_utterances_through_the_table(full_pack, oracle_mod):
           f"{st['admissions']}, decoder calls {st['decode_calls']}; sampled per-frame latent max-abs vs int8 oracle {worst:.3e}, vs f32 oracle {worst_f:.3e}")
     assert worst <= 1.5 * worst_f and worst <= 3e-1
     eng.close()
+
+
+def test_two_engines_behind_one_handle(packs, oracle_mod, monkeypatch):
+    """POCKET_TTS_DEVICES lists the GPUs of one handle; listing GPU 0 twice builds two engines on the one GPU of the test box
+    (the second runs its flow head as a launch chain: one persistent head per GPU).  A queued batch is dealt out over both,
+    single calls go to the engine with fewer utterances pending, and every utterance equals the oracle's replay."""
+    import ptts_lib as ptts
+    monkeypatch.setenv("POCKET_TTS_DEVICES", "0,0")
+    path, spec, _ = packs["tiny_eos"]
+    F = 40
+    eng = ptts.Engine(path, precision="fp32", temperature=0.0, lsd_steps=4, max_frames=F)
+    o = oracle_mod.Oracle(path)
+    rng = np.random.default_rng(77)
+    ids, voices = _ragged(spec, rng, 41)
+    res = eng.generate_ids(ids, voices, queued=True)
+    served = eng.engine_served()
+    assert len(served) == 2 and sorted(served) == [20, 21], served
+    for i in range(41):
+        lat, eos, frames = oracle_replay(o, ids[i], voices[i], res[i]["latents"], 4, F)
+        assert res[i]["frames"] == frames, i
+        if frames:
+            assert np.abs(res[i]["latents"] - lat).max() < 1e-3
+    # concurrent single calls spread over both engines
+    out = [None] * 8
+
+    def one(i):
+        out[i] = eng.generate_ids([ids[i]], [voices[i]])[0]
+    th = [threading.Thread(target=one, args=(i,)) for i in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(8):
+        assert out[i]["frames"] == res[i]["frames"]
+        np.testing.assert_allclose(out[i]["latents"], res[i]["latents"], rtol=0, atol=1e-4)
+    after = eng.engine_served()
+    assert sum(after) == 49 and min(after) > min(served), after
+    eng.close()
