@@ -586,9 +586,19 @@ void Engine::encode_enqueue(const float* const* clips, int B, int S, int slot) {
     float* xe = take(Bz * (rk - 1 + T) * c);
     size_t xe_seg = static_cast<size_t>(rk - 1 + T);            // rows per clip in xe; its first rows are the causal left padding
     int xe_pad = rk - 1;
-    zero_rows(xe, xe_seg, 0, xe_pad, c);
-    launch_conv_from_mono(dau, S, nullptr, T, s.kernel, c, hd_.enc_conv0_w, hd_.enc_conv0_b, xraw, static_cast<long long>(T) * c,
-                          xe + static_cast<size_t>(xe_pad) * c, static_cast<long long>(xe_seg) * c, B, stream_);
+    // the first convolution and the residual unit behind it in one launch where the shapes allow (64 / 32 channels)
+    EncStage0Args e0;
+    e0.audio = dau; e0.a_bs = S; e0.T = T; e0.B = B; e0.k = s.kernel; e0.c0 = c; e0.c1 = c / 2; e0.rk = rk;
+    e0.w0 = hd_.enc_conv0_w; e0.b0 = hd_.enc_conv0_b;
+    e0.w1_hi = hd_.enc_c1[0].lo ? hd_.enc_c1[0].p : nullptr; e0.w1_lo = hd_.enc_c1[0].lo; e0.b1 = hd_.enc_c1_b[0];
+    e0.w2_hi = hd_.enc_c2[0].lo ? hd_.enc_c2[0].p : nullptr; e0.w2_lo = hd_.enc_c2[0].lo; e0.b2 = hd_.enc_c2_b[0];
+    e0.out = reinterpret_cast<float*>(16); e0.out_bs = 0;       // placeholder for the shape check; set per stage below
+    const bool fused0 = !std::getenv("POCKET_TTS_NO_FUSED_ENCODER_STAGE") && enc_stage0_supported(e0);
+    if (!fused0) {
+        zero_rows(xe, xe_seg, 0, xe_pad, c);
+        launch_conv_from_mono(dau, S, nullptr, T, s.kernel, c, hd_.enc_conv0_w, hd_.enc_conv0_b, xraw, static_cast<long long>(T) * c,
+                              xe + static_cast<size_t>(xe_pad) * c, static_cast<long long>(xe_seg) * c, B, stream_);
+    }
     for (int i = 0; i < 3; ++i) {
         const int r = s.ratios[2 - i], To = (T + r - 1) / r, Tpad = To * r;
         float* h1 = take(Bz * T * (c / 2));
@@ -597,7 +607,7 @@ void Engine::encode_enqueue(const float* const* clips, int B, int S, int slot) {
          c1.bias = hd_.enc_c1_b[i];
         c1.M = B * T; c1.N = c / 2; c1.K = rk * c; c1.C = h1; c1.ldc = c / 2; c1.c_bs = static_cast<long long>(T) * (c / 2); c1.c_act = ACT_ELU;
         hd_.enc_c1[i].bind(c1, c1.M);
-        launch_gemm(c1, stream_);
+        if (!(fused0 && i == 0)) launch_gemm(c1, stream_);
         // rows [r, r + T) of a clip's segment are written by the product below; the padding before and after them stays zero
         const size_t ye_seg = static_cast<size_t>(r + Tpad);
         float* ye = take(Bz * ye_seg * c);
@@ -609,7 +619,12 @@ void Engine::encode_enqueue(const float* const* clips, int B, int S, int slot) {
         c2.M = B * T; c2.N = c; c2.K = c / 2; c2.R = xraw; c2.ldr = c; c2.r_bs = static_cast<long long>(T) * c;
         c2.C = ye + static_cast<size_t>(r) * c; c2.ldc = c; c2.c_bs = static_cast<long long>(ye_seg) * c; c2.c_act = ACT_ELU;
         hd_.enc_c2[i].bind(c2, c2.M);
-        launch_gemm(c2, stream_);
+        if (fused0 && i == 0) {
+            e0.out = ye + static_cast<size_t>(r) * c; e0.out_bs = static_cast<long long>(ye_seg) * c;
+            launch_enc_stage0(e0, stream_);
+        } else {
+            launch_gemm(c2, stream_);
+        }
         const int pn = i < 2 ? rk - 1 : lk - 1;
         float* xraw2 = take(Bz * To * 2 * c);
         const size_t xe2_seg = static_cast<size_t>(pn + To);

@@ -147,6 +147,19 @@ void launch_conv_from_mono(const float* audio, long long a_bs, const int* len, i
                            const float* bias, float* raw, long long raw_bs, float* elu, long long elu_bs, int B,
                            hipStream_t s);
 
+// First stage of the voice encoder in one launch (encoder_fused.hip): out[b][t][64] = ELU(skip + conv1(ELU(conv3(ELU(x)))))
+// with x[b][t][64] = conv_k(audio[b]) (one input channel, causal), for t < T; rows the unit pads with are zero.
+struct EncStage0Args {
+    const float* audio = nullptr; long long a_bs = 0; int T = 0, B = 0;
+    int k = 0, c0 = 0, c1 = 0, rk = 0;                         // first convolution's taps; channels 64 / 32; unit kernel 3
+    const float* w0 = nullptr; const float* b0 = nullptr;      // [c0][k], [c0]
+    const void* w1_hi = nullptr; const void* w1_lo = nullptr; const float* b1 = nullptr;   // [c1][rk * c0] as two bf16 terms
+    const void* w2_hi = nullptr; const void* w2_lo = nullptr; const float* b2 = nullptr;   // [c0][c1]
+    float* out = nullptr; long long out_bs = 0;
+};
+bool enc_stage0_supported(const EncStage0Args& a);
+void launch_enc_stage0(const EncStage0Args& a, hipStream_t s);
+
 // Fused residual unit of a SEANet decoder stage (decoder_fused.hip):
 //   E[b][e_off + t][:] = ELU(y_t + W2 . ELU(W1 * ELU(y_{t-2..t}) + b1) + b2),  y_t = Y[b][t + 2][:]
 // Y holds the two previous rows of the stream in front of the chunk's T rows; bf16 weights, bf16 Y and E rows,
