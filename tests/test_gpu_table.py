@@ -229,9 +229,77 @@ def test_two_engines_behind_one_handle(packs, oracle_mod, monkeypatch):
         t.start()
     for t in th:
         t.join()
-    for i in range(8):
-        assert out[i]["frames"] == res[i]["frames"]
-        np.testing.assert_allclose(out[i]["latents"], res[i]["latents"], rtol=0, atol=1e-4)
+    for i in range(8):   # each against the oracle on its own history (free-running runs of one utterance may part ways)
+        lat, eos, frames = oracle_replay(o, ids[i], voices[i], out[i]["latents"], 4, F)
+        assert out[i]["frames"] == frames, i
+        if frames:
+            assert np.abs(out[i]["latents"] - lat).max() < 1e-3
     after = eng.engine_served()
     assert sum(after) == 49 and min(after) > min(served), after
+    eng.close()
+
+
+def test_more_callers_than_slots_mixed_traffic(packs):
+    """96 threads on one handle at once, more than the table has slots: streams with chunk sizes 1 to 20, single offline calls
+    and a few queued batches.  Every call returns (the test's time limit is the deadlock detector), chunks arrive in the
+    reference's schedule (full chunks, then at most one flagged tail), a stream's samples equal frames x samples per frame,
+    and afterwards the table is idle and serves a call as before.  The pack never raises EOS, so every utterance has
+    max_frames frames whatever company it is prefilled in (on the packs that stop early, rounding differences between
+    prefill passes of different sizes move a free-running utterance's stop frame; frame counts on those are checked with
+    the oracle on the same history in the tests above)."""
+    import ptts_lib as ptts
+    path, spec, _ = packs["tiny"]
+    F = 47
+    eng = ptts.Engine(path, precision="fp32", temperature=0.0, lsd_steps=4, max_frames=F)
+    rng = np.random.default_rng(404)
+    ids, voices = _ragged(spec, rng, 96)
+    ref = eng.generate_ids(ids, voices, queued=True, want_latents=False)
+    frames = [r["frames"] for r in ref]
+    errs, done = [], [0]
+    lock = threading.Lock()
+    gate = threading.Barrier(96)
+
+    def stream(i, chunk):
+        total, chunks, _ = eng.streaming_ids(ids[i], voices[i], chunk_frames=chunk)
+        assert total == frames[i] * spec.frame_size, (i, total, frames[i])
+        sizes = [len(c) // spec.frame_size for c, _ in chunks]
+        flags = [f for _, f in chunks]
+        assert sum(sizes) == frames[i]
+        assert all(s == chunk for s in sizes[:-1]) and all(f == 0 for f in flags[:-1]), (i, chunk, sizes, flags)
+        if sizes:
+            assert (flags[-1] == 1) == (sizes[-1] < chunk), (i, chunk, sizes, flags)   # only a tail remainder is flagged final
+
+    def offline(i):
+        r = eng.generate_ids([ids[i]], [voices[i]], want_latents=False)[0]
+        assert r["frames"] == frames[i] and len(r["audio"]) == frames[i] * spec.frame_size
+
+    def batch(i):
+        rs = eng.generate_ids(ids[i:i + 5], voices[i:i + 5], queued=True, want_latents=False)
+        assert [r["frames"] for r in rs] == frames[i:i + 5]
+
+    def run(i):
+        try:
+            gate.wait()
+            if i % 3 == 0:
+                stream(i, [1, 2, 5, 7, 15, 20][(i // 3) % 6])
+            elif i % 16 == 1:
+                batch(min(i, 90))
+            else:
+                offline(i)
+            with lock:
+                done[0] += 1
+        except Exception as e:   # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(96)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs[:3]
+    assert done[0] == 96
+    st = eng.scheduler_stats()
+    assert st["largest"] == 64                      # the table filled up and the rest waited for slots
+    again = eng.generate_ids([ids[0]], [voices[0]], want_latents=False)[0]
+    assert again["frames"] == frames[0]
     eng.close()
