@@ -105,4 +105,11 @@ struct DevBuf {
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Blocking copies and fills on a stream of their own.  The plain forms (hipMemcpy, hipMemset) run on the legacy stream,
+// and the runtime refuses any operation there while another thread of the process is capturing a graph ("would make the
+// legacy stream depend on a capturing blocking stream"): engines on several GPUs, or several on one, capture their frame
+// graphs while others are being created or are growing their buffers.
+void sync_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+void sync_fill(void* dst, int value, size_t bytes);
+
 }  // namespace ptts

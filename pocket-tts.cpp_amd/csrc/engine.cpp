@@ -129,7 +129,7 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
         }
     }
     blob_f32_.alloc(f32_bytes);
-    PTTS_HIP(hipMemcpy(blob_f32_.p, host.data(), f32_bytes, hipMemcpyHostToDevice));
+    sync_copy(blob_f32_.p, host.data(), f32_bytes, hipMemcpyHostToDevice);
     if (prec_ != Precision::FP32) {
         std::vector<uint16_t> lp(lp_bytes / 2, 0);
         auto conv = [&](size_t off_lp, const float* src, size_t n) {
@@ -140,7 +140,7 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
             if (entries_[n].has_lp) conv(entries_[n].off_lp, pack.get(n).data, pack.get(n).numel());
         conv(ada_off_lp, reinterpret_cast<const float*>(host.data() + ada_off_f32), ada_w_elems);
         blob_lp_.alloc(lp_bytes);
-        PTTS_HIP(hipMemcpy(blob_lp_.p, lp.data(), lp_bytes, hipMemcpyHostToDevice));
+        sync_copy(blob_lp_.p, lp.data(), lp_bytes, hipMemcpyHostToDevice);
         ada_all.p = static_cast<unsigned char*>(blob_lp_.p) + ada_off_lp;
         ada_all.wtype = W_BF16;
     } else {
@@ -172,10 +172,10 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
             bytes = pack_q8_weight(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), sc);
         }
         extra_.emplace_back(bytes.size());
-        PTTS_HIP(hipMemcpy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+        sync_copy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice);
         const void* wp = extra_.back().p;
         extra_.emplace_back(sc.size() * 4);
-        PTTS_HIP(hipMemcpy(extra_.back().p, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+        sync_copy(extra_.back().p, sc.data(), sc.size() * 4, hipMemcpyHostToDevice);
         scale_dev = static_cast<const float*>(extra_.back().p);
         return wp;
     };
@@ -183,7 +183,7 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
         const HostTensor& t = pack.get(name);
         auto bytes = pack_flow_weight(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), flow_wtype);
         extra_.emplace_back(bytes.size());
-        PTTS_HIP(hipMemcpy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+        sync_copy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice);
         return extra_.back().p;
     };
     flow_in_packed = packed("flow.in_proj.w");
@@ -198,7 +198,7 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
         if (mod_width % 16 == 0 && C % kstep == 0) {
             auto bytes = pack_flow_weight(reinterpret_cast<const float*>(host.data() + ada_off_f32), mod_width, C, flow_wtype);
             extra_.emplace_back(bytes.size());
-            PTTS_HIP(hipMemcpy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+            sync_copy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice);
             ada_packed = extra_.back().p;
         }
     }
@@ -214,7 +214,7 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
             if (t.shape.size() != 2 || t.shape[0] % 16 || t.shape[1] % (wt == W_BF16 ? 32 : 16)) continue;
             auto bytes = pack_flow_weight(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), wt);
             extra_.emplace_back(bytes.size());
-            PTTS_HIP(hipMemcpy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+            sync_copy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice);
             frag_[n] = extra_.back().p;
         }
     }
@@ -246,10 +246,10 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
                 lo[i] = to_bf16(t.data[i] - hf);
             }
             extra_.emplace_back(el * 2);
-            PTTS_HIP(hipMemcpy(extra_.back().p, hi.data(), el * 2, hipMemcpyHostToDevice));
+            sync_copy(extra_.back().p, hi.data(), el * 2, hipMemcpyHostToDevice);
             const void* ph = extra_.back().p;
             extra_.emplace_back(el * 2);
-            PTTS_HIP(hipMemcpy(extra_.back().p, lo.data(), el * 2, hipMemcpyHostToDevice));
+            sync_copy(extra_.back().p, lo.data(), el * 2, hipMemcpyHostToDevice);
             split_[n] = {ph, extra_.back().p};
         }
     }
@@ -258,7 +258,7 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
         if (t.shape.size() == 2 && t.shape[0] % 16 == 0 && t.shape[1] % 16 == 0) {
             auto bytes = pack_flow_weight(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), W_F32);
             extra_.emplace_back(bytes.size());
-            PTTS_HIP(hipMemcpy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+            sync_copy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice);
             enc_ds_packed = extra_.back().p;
         }
     }
@@ -371,10 +371,10 @@ void Model::build_rope_tables(int lm_len, int mimi_len) {
     size_t lb = align256(lc.size() * 4), mb = align256(mc.size() * 4);
     rope_.alloc(2 * lb + 2 * mb);
     auto* base = static_cast<unsigned char*>(rope_.p);
-    PTTS_HIP(hipMemcpy(base, lc.data(), lc.size() * 4, hipMemcpyHostToDevice));
-    PTTS_HIP(hipMemcpy(base + lb, ls.data(), ls.size() * 4, hipMemcpyHostToDevice));
-    PTTS_HIP(hipMemcpy(base + 2 * lb, mc.data(), mc.size() * 4, hipMemcpyHostToDevice));
-    PTTS_HIP(hipMemcpy(base + 2 * lb + mb, ms.data(), ms.size() * 4, hipMemcpyHostToDevice));
+    sync_copy(base, lc.data(), lc.size() * 4, hipMemcpyHostToDevice);
+    sync_copy(base + lb, ls.data(), ls.size() * 4, hipMemcpyHostToDevice);
+    sync_copy(base + 2 * lb, mc.data(), mc.size() * 4, hipMemcpyHostToDevice);
+    sync_copy(base + 2 * lb + mb, ms.data(), ms.size() * 4, hipMemcpyHostToDevice);
     lm_cos = reinterpret_cast<const float*>(base);
     lm_sin = reinterpret_cast<const float*>(base + lb);
     mimi_cos = reinterpret_cast<const float*>(base + 2 * lb);
@@ -439,7 +439,7 @@ Batch::Batch(Engine& e, int B_, bool lm_only_) : B(B_), Bw(B_), lm_only(lm_only_
     mods.alloc(static_cast<size_t>(o.lsd_steps) * B * e.model().mod_width * 4);
     flow_ws.alloc(flow_head_workspace_bytes(B, C, e.model().flow_wtype, s.flow_blocks));
     flow_ctl.alloc(flow_ring_ctl_bytes(B, s.flow_blocks));
-    PTTS_HIP(hipMemset(flow_ctl.p, 0, flow_ctl.bytes));   // the error word is read after every run, whichever form of the head ran
+    sync_fill(flow_ctl.p, 0, flow_ctl.bytes);   // the error word is read after every run, whichever form of the head ran
     // decoder activations
     if (!lm_only) {
     zbuf.alloc(static_cast<size_t>(B) * kDecChunk * L * 4);
@@ -469,7 +469,7 @@ Batch::Batch(Engine& e, int B_, bool lm_only_) : B(B_), Bw(B_), lm_only(lm_only_
     partial.alloc(static_cast<size_t>(16) * B * D * 4);   // up to 16 K-slice slabs, sized once: the frame graph holds the pointer
     if (e.model().lm_wtype == W_I8 && D % 64 == 0 && s.lm_ffn % 64 == 0 && D == s.lm_heads * 64) {
         q_rows = (B + 15) & ~15;
-        auto zeroed = [&](DevBuf& d, size_t bytes) { d.alloc(bytes); PTTS_HIP(hipMemset(d.p, 0, bytes)); };
+        auto zeroed = [&](DevBuf& d, size_t bytes) { d.alloc(bytes); sync_fill(d.p, 0, bytes); };
         zeroed(hq, static_cast<size_t>(B) * D); zeroed(hd, static_cast<size_t>(D / 64) * q_rows * 4);
         zeroed(attq, static_cast<size_t>(B) * D); zeroed(attd, static_cast<size_t>(s.lm_heads) * q_rows * 4);
         zeroed(ffq, static_cast<size_t>(B) * s.lm_ffn); zeroed(ffd, static_cast<size_t>(s.lm_ffn / 64) * q_rows * 4);
@@ -568,15 +568,18 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
             const bool to_dec = (i / 8) % 8 >= 8 - dec_eighths;
             (to_dec ? dec_mask : main_mask)[i / 32] |= 1u << (i % 32);
         }
+        // The frame loop's stream has the default priority.  Measured with two engines on one GPU: two high-priority
+        // streams ran their frames one after the other (4600 RTFx for both together against 6060 for one alone), two
+        // default-priority streams side by side (7600); one engine alone runs the same either way.
         if (frame_eighths >= 1) PTTS_HIP(hipExtStreamCreateWithCUMask(&stream_, words, main_mask.data()));
-        else PTTS_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
+        else PTTS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         if (hipExtStreamCreateWithCUMask(&dec_stream_, words, dec_mask.data()) != hipSuccess) {
             (void)hipGetLastError();   // masks unsupported here: an ordinary low-priority stream does the job, only slower
             PTTS_HIP(hipStreamCreateWithPriority(&dec_stream_, hipStreamNonBlocking, lo));
         }
     } else {
         // the frame loop's small dependent launches go ahead of the decoder's wide ones whenever both are ready
-        PTTS_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
+        PTTS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         PTTS_HIP(hipStreamCreateWithPriority(&dec_stream_, hipStreamNonBlocking, lo));
     }
     PTTS_HIP(hipEventCreateWithFlags(&latents_ready_, hipEventDisableTiming));
@@ -678,7 +681,7 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
     init_static_scratch();
     PTTS_TRACE("ctor: static scratch resolved");
     flow_te_.alloc(te.size() * 4);
-    PTTS_HIP(hipMemcpy(flow_te_.p, te.data(), te.size() * 4, hipMemcpyHostToDevice));
+    sync_copy(flow_te_.p, te.data(), te.size() * 4, hipMemcpyHostToDevice);
     PTTS_HIP(hipEventCreate(&ev_[0]));
     PTTS_HIP(hipEventCreate(&ev_[1]));
     PTTS_TRACE("ctor: done");
@@ -1080,9 +1083,9 @@ void Engine::flow_scratch_layout(int rows, size_t off[6]) const {
 void Engine::check_flow_ring(const unsigned* ctl, int rows) {
     if (!ctl || model_->flow_wtype != W_BF16 || spec().flow_dim != 512) return;
     unsigned err = 0;
-    PTTS_HIP(hipMemcpy(&err, ctl + flow_ring_err_word(rows, spec().flow_blocks), 4, hipMemcpyDeviceToHost));
+    sync_copy(&err, ctl + flow_ring_err_word(rows, spec().flow_blocks), 4, hipMemcpyDeviceToHost);
     if (err) {
-        PTTS_HIP(hipMemset(const_cast<unsigned*>(ctl), 0, 4));
+        sync_fill(const_cast<unsigned*>(ctl), 0, 4);
         throw std::runtime_error("flow head: a hand-off between workgroups timed out (the persistent launch was not fully resident)");
     }
 }

@@ -486,7 +486,7 @@ int Engine::generate_streaming_inline(const Utterance& utt, int chunk_frames, co
     if (capture) {
         capture->frames = frames - pending;
         capture->latents.resize(static_cast<size_t>(frames) * L);
-        if (frames) PTTS_HIP(hipMemcpy(capture->latents.data(), b.latents.p, capture->latents.size() * 4, hipMemcpyDeviceToHost));
+        if (frames) sync_copy(capture->latents.data(), b.latents.p, capture->latents.size() * 4, hipMemcpyDeviceToHost);
     }
     return total;
 }

@@ -22,8 +22,8 @@ namespace pocket_tts {
 struct PocketTTS::Impl {
     PocketTTSConfig config;
     std::unique_ptr<ptts::Engine> engine;
-    // POCKET_TTS_DEVICES=0,1,...: one more engine (weights, slot table, worker thread) per further device behind this one
-    // handle; single utterances and streams go to the engine with the fewest utterances pending, queued batches are dealt
+    // POCKET_TTS_DEVICES=0,1,...: one more engine (weights, slot table, worker thread) per further entry behind this one
+    // handle (an ordinal may repeat: several engines on one GPU); single utterances and streams go to the engine with the fewest utterances pending, queued batches are dealt
     // out over all of them.  `engine` is the first listed device and serves everything else (operators, voice encoding).
     std::vector<std::unique_ptr<ptts::Engine>> more;
     std::unique_ptr<Tokenizer> tokenizer;
@@ -53,6 +53,15 @@ struct PocketTTS::Impl {
             for (std::string tok; std::getline(ss, tok, ',');)
                 if (!tok.empty()) devices.push_back(std::stoi(tok));
         }
+        // POCKET_TTS_ENGINES_PER_GPU=n (without a device list): n engines on the configured device, each with its own slot
+        // table and streams.  A frame step is bound by the latency of its dependent launches, not by the chip, so two
+        // tables side by side serve about a quarter more audio per second than one (the first holds the persistent flow
+        // head, the others run the head as a launch chain).  At most 3: measured on MI355X, 512 utterances of 125 frames,
+        // int8 5060 / 6550 / 7520 / 7080 RTFx with 1 / 2 / 3 / 4 engines, bf16 5620 / 7080 / 7240; beyond three the streams of
+        // the engines no longer get a hardware queue each (GPU_MAX_HW_QUEUES is 4 by default).
+        if (devices.empty())
+            if (const char* e = std::getenv("POCKET_TTS_ENGINES_PER_GPU"))
+                devices.assign(static_cast<size_t>(std::max(1, std::min(std::atoi(e), 3))), cfg.device);
         if (!devices.empty()) o.device = devices[0];
         engine = std::make_unique<ptts::Engine>(o);
         for (size_t i = 1; i < devices.size(); ++i) {
@@ -61,7 +70,7 @@ struct PocketTTS::Impl {
             if (oi.has_seed) oi.seed += i;
             more.push_back(std::make_unique<ptts::Engine>(oi));
         }
-        if (cfg.verbose && !more.empty()) std::cout << "Engines on " << devices.size() << " devices." << std::endl;
+        if (cfg.verbose && !more.empty()) std::cout << devices.size() << " engines behind this handle." << std::endl;
         if (cfg.loadTokenizer) {
             tokenizer = std::make_unique<Tokenizer>(cfg.tokenizerPath);
             if (cfg.verbose) std::cout << "Tokenizer loaded (vocab size: " << tokenizer->vocabSize() << ")." << std::endl;

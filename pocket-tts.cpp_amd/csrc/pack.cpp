@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace ptts {
 
@@ -37,6 +38,36 @@ void trace_fmt(const char* fmt, ...) {
     va_end(ap);
     const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     std::fprintf(stderr, "[pocket-tts %lld.%03lld ms] %s\n", static_cast<long long>(us / 1000 % 100000), static_cast<long long>(us % 1000), buf);
+}
+
+namespace {
+// one stream per device, made on first use and kept for the life of the process; the mutex also orders the callers
+std::mutex g_util_mu;
+hipStream_t g_util_stream[64];
+
+hipStream_t util_stream_locked() {
+    int dev = 0;
+    PTTS_HIP(hipGetDevice(&dev));
+    hipStream_t& s = g_util_stream[dev & 63];
+    if (!s) PTTS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
+}  // namespace
+
+void sync_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    if (bytes == 0) return;
+    std::lock_guard<std::mutex> g(g_util_mu);
+    hipStream_t s = util_stream_locked();
+    PTTS_HIP(hipMemcpyAsync(dst, src, bytes, kind, s));
+    PTTS_HIP(hipStreamSynchronize(s));
+}
+
+void sync_fill(void* dst, int value, size_t bytes) {
+    if (bytes == 0) return;
+    std::lock_guard<std::mutex> g(g_util_mu);
+    hipStream_t s = util_stream_locked();
+    PTTS_HIP(hipMemsetAsync(dst, value, bytes, s));
+    PTTS_HIP(hipStreamSynchronize(s));
 }
 
 Pack::Pack(const std::string& path) {

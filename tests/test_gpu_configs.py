@@ -148,6 +148,36 @@ def test_long_form_500_frames(env, precision):
     eng.close()
 
 
+def test_two_tables_side_by_side_on_one_gpu(env, monkeypatch):
+    """POCKET_TTS_ENGINES_PER_GPU=2: two engines (two slot tables, two frame-loop streams) on the one GPU behind one handle, the
+    first with the persistent flow head, the second running the head as a launch chain.  A queue of 130 utterances is dealt
+    out evenly; utterances served by either engine equal the oracle's replay on their own history (bf16 bound 2e-2)."""
+    lib, spec = env["lib"], env["spec"]
+    monkeypatch.setenv("POCKET_TTS_ENGINES_PER_GPU", "2")
+    F, N = 12, 130
+    eng = lib.Engine(env["path"], precision="bf16", temperature=0.0, lsd_steps=10, max_frames=F)
+    o = env["mod"].Oracle(env["path_q"])
+    rng = np.random.default_rng(5)
+    ids = [rng.integers(0, spec.vocab, int(rng.integers(6, 33))).astype(np.int64) for _ in range(N)]
+    voices = [(rng.standard_normal((int(rng.integers(20, 63)), spec.d_model)) * 0.5).astype(np.float32) for _ in range(N)]
+    res = eng.generate_ids(ids, voices, queued=True)
+    assert eng.engine_served() == [N // 2, N // 2]
+    st = eng.scheduler_stats()
+    assert st["utterances"] == N and st["frames"] == N * F
+    for i in range(N):
+        assert res[i]["frames"] == F and np.isfinite(res[i]["audio"]).all()
+    check = {0, 1, F - 2, F - 1}
+    worst = [0.0, 0.0]
+    for i in (0, 1, 128, 129):   # even indices went to one engine, odd ones to the other
+        rep = _replay_selected(o, ids[i], voices[i], res[i]["latents"], 10, check)
+        for k, (lat, e) in rep.items():
+            worst[i % 2] = max(worst[i % 2], float(np.abs(res[i]["latents"][k] - lat).max()), abs(float(res[i]["eos"][k]) - e))
+    _note(f"bf16 full size, two engines on one GPU, 130 queued utterances: per-frame latent/eos max-abs {worst[0]:.3e} (engine of the even "
+          f"indices), {worst[1]:.3e} (engine of the odd indices)")
+    assert max(worst) <= 2e-2
+    eng.close()
+
+
 _SCALED_RESULTS = {}
 
 
