@@ -44,17 +44,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
 
 constexpr int kThreads = 256, kWaves = 4;
-constexpr int C = 512, L = 32, G = 8;
-constexpr int KSTEP = 32, NT = C / 16, NT1 = NT / G, KS = C / KSTEP, KS2 = KS / G, CS = C / G;
+constexpr int C = 512, L = 32, kMaxG = 8;
+constexpr int KSTEP = 32, NT = C / 16, KS = C / KSTEP;
 // Row pitches of the A-operand planes: 64 bytes past a multiple of 256, so that the 16 pieces (4 rows x 4 k-groups) one
 // fragment read touches fall on 16 different groups of 4 banks.
-constexpr int LDA = C + 32, LDA2 = CS + 32, LDX = L + 8;
+constexpr int LDA = C + 32, LDX = L + 8;
+constexpr int lda2_of(int g) { return C / g + 32; }
 constexpr int NTL = L / 16, KPARTS = kWaves / NTL, KSP = KS / KPARTS;   // output projection: K split over the waves
 constexpr int kCtlStride = 32;                               // words between counters: one 128-byte line each
 constexpr unsigned kSpinLimit = 600000u;
 constexpr int kTw = 128 + 8;                                 // row pitch of the per-wave transpose buffer (floats)
 constexpr int T2 = NT / kWaves, TI = NT / kWaves;            // fc2 / input-projection tiles per wave
-static_assert(NT1 == kWaves && KS2 == 2 && KSP == 8 && NTL == 2 && T2 == 8, "flow ring: tiling written for flow_dim 512, latent 32, 8 slices, 4 waves");
+static_assert(KSP == 8 && NTL == 2 && T2 == 8, "flow ring: tiling written for flow_dim 512, latent 32, 4 waves");
 
 // v * sigmoid(v) on the hardware exp2 / reciprocal (about 1 ulp each): this form serves the bf16 engine only
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f)); }
@@ -147,9 +148,13 @@ struct FlowRingArgs {
     long long* stamps;                   // optional [16]: cycle counter along one mid-chain visit (tuning aid)
 };
 
-// RPG: utterance rows per row group (one wave per row in the element-wise phases).
-template <int RPG>
+// RPG: utterance rows per row group (one wave per row in the element-wise phases).  G: workgroups per residual block
+// (column slices of fc1 = K-slices of fc2): 4 keeps 256 registers of matrices per lane and halves the partial slabs a
+// visit reads and the number of consumers that read them; 8 keeps 128.
+template <int RPG, int G>
 __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
+    constexpr int NT1 = NT / G, NW1 = NT1 / kWaves, KS2 = KS / G, CS = C / G, LDA2 = lda2_of(G);
+    static_assert(NW1 >= 1 && NW1 * kWaves == NT1 && KS2 * G == KS, "flow ring: slices must divide the tiles of fc1 and the k-steps of fc2");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* hbuf = (float*)smem;                              // [RPG][C] f32: input-projection result; K-part sums of the output projection
     __bf16* A0 = (__bf16*)(hbuf + RPG * C);                   // [2][RPG][LDA]
@@ -177,11 +182,14 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
 
     // ---- this workgroup's matrices, once: fc1 tile `wave` of slice g over all of K; fc2 tiles 8 * wave .. 8 * wave + 7
     // (128 consecutive columns: four whole 128-byte lines of every output row) for K-slice g
-    uint4 wf1[KS], wf2[T2][KS2];
+    uint4 wf1[NW1][KS], wf2[T2][KS2];
     {
-        const uint4* w1p = (const uint4*)a.w1[blk] + ((long long)(g * NT1 + wave) * KS) * 64 + lane;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wf1[ks] = w1p[ks * 64];
+        for (int t = 0; t < NW1; ++t) {
+            const uint4* w1p = (const uint4*)a.w1[blk] + ((long long)(g * NT1 + wave * NW1 + t) * KS) * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wf1[t][ks] = w1p[ks * 64];
+        }
         const uint4* w2p = (const uint4*)a.w2[blk] + (long long)(g * KS2) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < T2; ++i) {
@@ -189,7 +197,9 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
             for (int ks = 0; ks < KS2; ++ks) wf2[i][ks] = w2p[((long long)(T2 * wave + i) * KS + ks) * 64];
         }
     }
-    const float bias1 = a.b1[blk][g * CS + wave * 16 + ccol];
+    float bias1[NW1];
+#pragma unroll
+    for (int t = 0; t < NW1; ++t) bias1[t] = a.b1[blk][g * CS + (wave * NW1 + t) * 16 + ccol];
     // block 0 also needs the input projection (tiles wave, wave + 4, ...) and its share of the output projection: in LDS,
     // fragment-major as in global memory, so a wave's read of one fragment is 1 KB contiguous
     float bin[TI];
@@ -381,13 +391,15 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
             }
             __syncthreads();
             RING_STAMP(4);
-            // ---- fc1: this workgroup's 64 columns, one tile per wave over all of K
+            // ---- fc1: this workgroup's C / G columns, NW1 tiles per wave over all of K
             {
                 // groups of 4 k-steps: the fragment reads of group n + 1 are issued before the MFMAs of group n (the pins keep
                 // the compiler from sinking each read to its use, which exposes one LDS latency per MFMA pair)
                 constexpr int GK = 4, NG = KS / GK;
                 bf16x8 fh[2][GK], fl[2][GK];
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 acc[NW1];
+#pragma unroll
+                for (int t = 0; t < NW1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < GK; ++k) { fh[0][k] = afrag<RPG>(A0, LDA, k * KSTEP, lane); fl[0][k] = afrag<RPG>(A1, LDA, k * KSTEP, lane); }
 #pragma unroll
@@ -402,11 +414,17 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int k = 0; k < GK; ++k) mma2(fh[n & 1][k], fl[n & 1][k], wf1[n * GK + k], acc);
+                    for (int k = 0; k < GK; ++k) {
+#pragma unroll
+                        for (int t = 0; t < NW1; ++t) mma2(fh[n & 1][k], fl[n & 1][k], wf1[t][n * GK + k], acc[t]);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const int cl = wave * 16 + ccol;
-                put1(S0, S1, lq * LDA2 + cl, silu_f(own_row(acc, lq) + bias1));
+#pragma unroll
+                for (int t = 0; t < NW1; ++t) {
+                    const int cl = (wave * NW1 + t) * 16 + ccol;
+                    put1(S0, S1, lq * LDA2 + cl, silu_f(own_row(acc[t], lq) + bias1[t]));
+                }
             }
             __syncthreads();
             RING_STAMP(5);
@@ -465,8 +483,15 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
 
 // ------------------------------------------------------------------------------------------------ host side
 
+// Workgroups per residual block: 4 by default, FLOW_RING_SLICES=8 selects the earlier form.
+static int ring_slices() {
+    static const int g = [] { const char* e = std::getenv("FLOW_RING_SLICES"); return e && std::atoi(e) == 8 ? 8 : 4; }();
+    return g;
+}
+
 bool flow_ring_supported(const FlowHeadArgs& a) {
     if (std::getenv("FLOW_HEAD_NO_RING")) return false;
+    const int G = ring_slices();
     const int bw = a.block_wtype < 0 ? a.wtype : a.block_wtype;
     return a.C == C && a.L == L && a.wtype == W_BF16 && bw == W_BF16 && a.blocks >= 2 && a.blocks <= kFlowRingMaxBlocks && a.steps >= 1 &&
            a.ring_ctl != nullptr && a.B >= 1 && a.ring_wg_budget >= a.blocks * G;
@@ -475,10 +500,12 @@ bool flow_ring_supported(const FlowHeadArgs& a) {
 // Row-group height and replica count for B rows.  More replicas shorten each workgroup's queue of row groups; the
 // chain of one row group (steps * blocks hand-offs) is the floor.  FLOW_RING_REPLICAS overrides.
 static void flow_ring_shape(int B, int blocks, int budget, int& rpg, int& replicas) {
+    const int G = ring_slices();
     rpg = 4;   // one row per wave
     const int ngroups = (B + rpg - 1) / rpg;
-    // measured at B = 64 beside the decoder stream: 2 replicas 0.65 ms per flow phase, 3 0.49, 4 0.43 (launch chain 0.54)
-    replicas = 4;
+    // measured at B = 64 beside the decoder stream with 8 slices: 2 replicas 0.65 ms per flow phase, 3 0.49, 4 0.43 (launch
+    // chain 0.54); the same 192 workgroups make 8 replicas of 4 slices
+    replicas = G == 8 ? 4 : 8;
     if (const char* e = std::getenv("FLOW_RING_REPLICAS")) replicas = std::atoi(e);
     const int max_rep = budget / (blocks * G);     // every workgroup must be resident at once; leave CUs for other streams
     if (replicas > max_rep) replicas = max_rep;
@@ -486,7 +513,7 @@ static void flow_ring_shape(int B, int blocks, int budget, int& rpg, int& replic
     if (replicas < 1) replicas = 1;
 }
 
-size_t flow_ring_workspace_bytes(int B, int blocks) { return (size_t)blocks * (1 + G) * B * C * sizeof(float); }
+size_t flow_ring_workspace_bytes(int B, int blocks) { return (size_t)blocks * (1 + kMaxG) * B * C * sizeof(float); }   // sized for either form
 
 size_t flow_ring_ctl_bytes(int B, int blocks) {
     const int ngroups = (B + 3) / 4;   // the smaller row-group height
@@ -500,6 +527,7 @@ size_t flow_ring_counter_word() { return kCtlStride; }
 
 static size_t ring_smem(int rpg, int ngroups, int replicas) {
     const int local = (ngroups + replicas - 1) / replicas;
+    const int LDA2 = lda2_of(ring_slices());
     return (size_t)rpg * C * 4 + (size_t)2 * rpg * (LDA + LDA2 + LDX) * 2 + (size_t)kWaves * rpg * kTw * 4 + (size_t)local * rpg * L * 4 + 16 +
            (size_t)(NT + NTL * KS) * 64 * 16;
 }
@@ -514,7 +542,8 @@ static void ring_lds_limit(const void* kernel) {
 }
 
 void flow_ring_prepare() {
-    ring_lds_limit((const void*)flow_ring_kernel<4>);
+    if (ring_slices() == 8) ring_lds_limit((const void*)flow_ring_kernel<4, 8>);
+    else ring_lds_limit((const void*)flow_ring_kernel<4, 4>);
 }
 
 // The caller has zeroed a.ring_ctl (flow_ring_ctl_bytes) earlier on the same stream.
@@ -542,9 +571,11 @@ void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s) {
     r.stamps = a.cycle_probe;
     const size_t smem = ring_smem(rpg, r.ngroups, replicas);
     if (smem > 160 * 1024) throw std::runtime_error("flow ring: LDS request too large");
+    const int G = ring_slices();
     const int grid = replicas * a.blocks * G;
     if (a.probe_a) (void)hipEventRecord(a.probe_a, s);
-    hipLaunchKernelGGL(flow_ring_kernel<4>, dim3(grid), dim3(kThreads), smem, s, r);
+    if (G == 8) hipLaunchKernelGGL((flow_ring_kernel<4, 8>), dim3(grid), dim3(kThreads), smem, s, r);
+    else hipLaunchKernelGGL((flow_ring_kernel<4, 4>), dim3(grid), dim3(kThreads), smem, s, r);
     if (a.probe_b) (void)hipEventRecord(a.probe_b, s);
 }
 
