@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects on a GPU box what profiles/ holds for one round (argument: the prefix, e.g. r02): rocprofv3 per-kernel
 # statistics of the bench command on its default path (one hipGraph per frame), the two HBM counter passes, the bench
-# lines (default workload with its extra legs, and --workload c4), per-kernel statistics of the int8 engine with eager
+# lines (default workload with its extra legs, and --workload c4 with two engines, one engine, and bf16), per-kernel statistics of the int8 engine with eager
 # launches, the streaming latency probe, the encode throughput and the parity notes of
 # the full-size tests.  Every GPU step has its own time limit and the script stops at the first failure.
 # Under rocprofv3 7.2 the first hipGraphLaunch of a frame graph segfaults now and then inside the profiler's queue hook
@@ -35,6 +35,9 @@ cp "$(ls "$OUT"/stats_i8/*/*kernel_stats.csv | head -1)" "$OUT/${R}_kernel_stats
 rm -rf "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/stats" "$OUT/stats_i8" "$OUT/pmc_fetch.log" "$OUT/pmc_write.log" "$OUT/stats_i8_run.log"
 timeout -k 10 600 python3 bench.py > "$OUT/${R}_bench.json"
 timeout -k 10 600 python3 bench.py --workload c4 --no-cpu-baseline > "$OUT/${R}_bench_c4.json"
+timeout -k 10 600 python3 bench.py --workload c4 --no-cpu-baseline --no-extras --engines-per-gpu 1 > "$OUT/${R}_bench_c4_one_engine.json"
+timeout -k 10 600 python3 bench.py --workload c4 --no-cpu-baseline --no-extras --precision bf16 > "$OUT/${R}_bench_c4_bf16.json"
+if [ -x pocket-tts.cpp_amd/xcd_probe ]; then timeout -k 5 60 pocket-tts.cpp_amd/xcd_probe > "$OUT/${R}_xcd_probe.txt"; fi
 timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/latency_probe.py --runs 20 > "$OUT/${R}_latency_fp32.json"
 timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/latency_probe.py --runs 20 --precision bf16 > "$OUT/${R}_latency_bf16.json"
 timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/latency_probe.py --runs 20 --precision int8 > "$OUT/${R}_latency_int8.json"
