@@ -198,34 +198,57 @@ void Engine::submit(Request& r) {
     submit_all(&one, 1);
 }
 
-// Validates and prepares every request, then queues them all at once (a burst joins the table in one admission).
+// Validates every request, then prepares and queues them in waves of one table's worth: a burst of up to 64 joins the
+// table in one admission, and the start points of a longer queue are drawn while the table already serves the first wave
+// (4000 normal deviates per utterance at 125 frames: 0.1 ms each on one core, drawn on up to 8 threads).
 void Engine::submit_all(Request* const* reqs, size_t n) {
     for (size_t i = 0; i < n; ++i) validate_request(reqs[i]->utt);   // fail before anything is queued
     PTTS_TRACEF("submit: %d (%s)", static_cast<int>(n), n && reqs[0]->streaming ? "stream" : "offline");
-    for (size_t i = 0; i < n; ++i) {
-        Request& r = *reqs[i];
-        if (r.utt.noise || !(opt_.temperature > 0)) continue;
+    const int L = spec().latent;
+    const size_t per = static_cast<size_t>(opt_.max_frames) * L;
+    const float sd = std::sqrt(std::max(opt_.temperature, 0.0f));
+    auto draw = [&](Request& r, uint32_t seed) {
         // N(0, sqrt(T)) from a fresh distribution object per frame (src/pocket_tts.cpp:606-613), drawn up front
-        const int L = spec().latent;
-        r.noise.resize(static_cast<size_t>(opt_.max_frames) * L);
-        std::mt19937 gen;
-        {
-            std::lock_guard<std::mutex> lk(q_mu_);
-            gen.seed(rng_());
-        }
+        r.noise.resize(per);
+        std::mt19937 gen(seed);
         for (int f = 0; f < opt_.max_frames; ++f) {
-            std::normal_distribution<float> dist(0.0f, std::sqrt(opt_.temperature));
+            std::normal_distribution<float> dist(0.0f, sd);
             for (int k = 0; k < L; ++k) r.noise[static_cast<size_t>(f) * L + k] = dist(gen);
         }
+    };
+    for (size_t first = 0; first < n; first += kSlots) {
+        const size_t count = std::min(n - first, static_cast<size_t>(kSlots));
+        std::vector<Request*> need;
+        std::vector<uint32_t> seeds;
+        if (opt_.temperature > 0) {
+            std::lock_guard<std::mutex> lk(q_mu_);
+            for (size_t i = 0; i < count; ++i)
+                if (!reqs[first + i]->utt.noise) { need.push_back(reqs[first + i]); seeds.push_back(static_cast<uint32_t>(rng_())); }   // seeds in request order
+        }
+        const size_t workers = std::min<size_t>({need.size() / 4, 8, std::max(1u, std::thread::hardware_concurrency())});
+        if (workers > 1) {
+            std::vector<std::thread> pool;
+            for (size_t w = 0; w < workers; ++w)
+                pool.emplace_back([&, w] { for (size_t i = w; i < need.size(); i += workers) draw(*need[i], seeds[i]); });
+            for (auto& t : pool) t.join();
+        } else {
+            for (size_t i = 0; i < need.size(); ++i) draw(*need[i], seeds[i]);
+        }
+        std::unique_lock<std::mutex> lk(q_mu_);
+        if (worker_stop_) {
+            if (first == 0) throw std::runtime_error("engine is shutting down");
+            // earlier waves are already queued and will be answered by the worker: the rest is answered here
+            lk.unlock();
+            for (size_t i = first; i < n; ++i) Table::finish(reqs[i], std::make_exception_ptr(std::runtime_error("engine is shutting down")));
+            return;
+        }
+        if (!worker_started_) {
+            worker_started_ = true;
+            worker_ = std::thread([this] { worker_main(); });
+        }
+        for (size_t i = 0; i < count; ++i) queue_.push_back(reqs[first + i]);
+        q_cv_.notify_all();
     }
-    std::lock_guard<std::mutex> lk(q_mu_);
-    if (worker_stop_) throw std::runtime_error("engine is shutting down");
-    if (!worker_started_) {
-        worker_started_ = true;
-        worker_ = std::thread([this] { worker_main(); });
-    }
-    for (size_t i = 0; i < n; ++i) queue_.push_back(reqs[i]);
-    q_cv_.notify_all();
 }
 
 namespace {

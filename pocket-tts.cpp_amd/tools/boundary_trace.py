@@ -1,0 +1,24 @@
+"""Tuning aid: one queued call of 64 utterances x 125 frames through the host boundary with POCKET_TTS_TRACE=1; the trace
+goes to stderr, the wall time of the call to stdout."""
+import os, sys, time, tempfile
+os.environ.setdefault("POCKET_TTS_TRACE", "1")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pyhost"))
+import numpy as np
+import ptts_pack as pp, ptts_lib
+
+spec = pp.Spec.full()
+path = os.path.join(tempfile.gettempdir(), "probe_full.ptts")
+pp.make_pack(path, spec, seed=1234, eos_bias=-20.0)
+eng = ptts_lib.Engine(path, precision="bf16", temperature=0.7, max_frames=125, seed=5)
+rng = np.random.default_rng(0)
+ids = [rng.integers(1, spec.vocab, size=32).astype(np.int64) for _ in range(64)]
+voices = [rng.standard_normal((62, spec.d_model)).astype(np.float32) * 0.1 for _ in range(64)]
+eng.generate_ids(ids, voices, queued=True, want_latents=False, want_audio=False)
+sys.stderr.write("==== timed call\n")
+t0 = time.perf_counter()
+eng.generate_ids(ids, voices, queued=True, want_latents=False, want_audio=False)
+dt = time.perf_counter() - t0
+sys.stderr.write("==== end\n")
+print("call ms", round(dt * 1e3, 2), "RTFx", round(64 * 125 * 0.08 / dt, 1))
+eng.close()
