@@ -1,8 +1,11 @@
 // extern "C" surface of libpocket_tts.so: the eleven drop-in entry points of pocket_tts_c.h and the
 // additive ones of pocket_tts_amd.h.  Conventions follow /root/reference/src/pocket_tts_c.cpp:
 // exceptions never cross the boundary, failures set a thread-local message (:11, :23-25, :159-161).
+#include <algorithm>
 #include <cstring>
+#include <exception>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "onnx_reader.h"
@@ -269,8 +272,28 @@ static int generate_ids_impl(PocketTTSHandle handle, int n, const long long* con
         } else {
             tts->engine().generate(utts, res, want);
         }
+        // the caller owns a copy of every utterance's samples (pocket_tts_free_audio): about 1 MB per 10 s of audio, copied on
+        // several threads when there are many
+        const int sr = tts->engine().spec().sample_rate;
+        const int copiers = results ? std::min({n / 8, 8, static_cast<int>(std::max(1u, std::thread::hardware_concurrency()))}) : 0;
+        if (copiers > 1) {
+            std::vector<std::thread> pool;
+            std::vector<std::exception_ptr> failed(copiers);
+            for (int i = 0; i < n; ++i) results[i].data = nullptr;
+            for (int w = 0; w < copiers; ++w)
+                pool.emplace_back([&, w] {
+                    try { for (int i = w; i < n; i += copiers) fill_result(&results[i], res[i].audio, sr); }
+                    catch (...) { failed[w] = std::current_exception(); }
+                });
+            for (auto& t : pool) t.join();
+            for (auto& f : failed)
+                if (f) {
+                    for (int i = 0; i < n; ++i) { delete[] results[i].data; results[i].data = nullptr; results[i].sample_count = 0; }
+                    std::rethrow_exception(f);
+                }
+        }
         for (int i = 0; i < n; ++i) {
-            if (results) fill_result(&results[i], res[i].audio, tts->engine().spec().sample_rate);
+            if (results && copiers <= 1) fill_result(&results[i], res[i].audio, sr);
             if (frames_out) frames_out[i] = res[i].frames;
             if (latents_out && latents_out[i] && !res[i].latents.empty())
                 std::memcpy(latents_out[i], res[i].latents.data(), res[i].latents.size() * 4);

@@ -95,7 +95,7 @@ struct Engine::Table {
     std::vector<Request*> due_reqs;
     size_t due_pushed = 0;
     std::thread d_thread;
-    int fs = 0, R = 0, L = 0, device = 0;
+    int fs = 0, R = 0, L = 0, F = 0, device = 0;
 
     void deliver_main();
     static void finish(Request* r, std::exception_ptr err = nullptr) {
@@ -145,6 +145,7 @@ void Engine::Table::deliver_main() {
                 const float* src = slabs[d.slab] + static_cast<size_t>(it.slot - d.slot0) * d.n * fs;
                 if (!r->streaming) {
                     std::vector<float>& a = r->out->audio;
+                    if (a.capacity() < static_cast<size_t>(F) * fs) a.reserve(static_cast<size_t>(F) * fs);   // one allocation per utterance
                     if (a.size() < static_cast<size_t>(it.f0 + it.n) * fs) a.resize(static_cast<size_t>(it.f0 + it.n) * fs);
                     std::memcpy(a.data() + static_cast<size_t>(it.f0) * fs, src, static_cast<size_t>(it.n) * fs * 4);
                 } else {
@@ -412,7 +413,7 @@ void Engine::run_table() {
         Table& N = *table_;
         N.b = std::make_unique<Batch>(*this, kSlots);
         N.pb = std::make_unique<Batch>(*this, kSlots, true);
-        N.fs = fs; N.R = N.b->lat_frames; N.L = L; N.device = opt_.device;
+        N.fs = fs; N.R = N.b->lat_frames; N.L = L; N.F = opt_.max_frames; N.device = opt_.device;
         for (auto& p : N.slabs) PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), static_cast<size_t>(kSlots) * kDecChunk * fs * 4));
         for (auto& p : N.h_lat) PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), static_cast<size_t>(kSlots) * N.R * L * 4));
         N.b->noise_all.alloc(static_cast<size_t>(kSlots) * N.R * L * 4);
