@@ -72,6 +72,9 @@ public:
     std::vector<float> generate(const std::string& text, const std::string& voicePath);
     // WAV -> conditioning rows, flattened [frames * d_model]
     std::vector<float> encodeVoice(const std::string& audioPath);
+    // Extension (no counterpart in the reference): encodeVoice over many files, the files prepared on host threads while the
+    // GPU encodes those already prepared; one embedding per path, in order, each also cached by path.
+    std::vector<std::vector<float>> encodeVoices(const std::vector<std::string>& audioPaths);
     // text + conditioning rows (shape [1, frames, d_model]) -> PCM
     std::vector<float> generateWithEmbeddings(const std::string& text, const std::vector<float>& voiceEmbeddings,
                                               const std::vector<int64_t>& voiceEmbeddingShape);

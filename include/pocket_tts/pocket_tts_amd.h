@@ -39,6 +39,12 @@ POCKET_TTS_API PocketTTSHandle pocket_tts_create_ex(const PocketTTSConfigEx* con
 /* dims[0..7] = latent_dim, d_model, samples_per_frame, vocab, mimi_dim, sample_rate, lsd_steps, max_frames */
 POCKET_TTS_API int pocket_tts_dims(PocketTTSHandle handle, int* dims);
 
+/* pocket_tts_encode_voice (/root/reference/include/pocket_tts/pocket_tts_c.h:63, src/pocket_tts_c.cpp:59-82) over n files in one
+   call: host threads decode / resample / attenuate / cut the files while the GPU encodes those already prepared.
+   voices_out[i] is what pocket_tts_encode_voice(handle, audio_paths[i]) returns (release with pocket_tts_free_voice);
+   on failure (-1, pocket_tts_get_last_error) every voices_out[i] is NULL. */
+POCKET_TTS_API int pocket_tts_encode_voices(PocketTTSHandle handle, int n, const char* const* audio_paths, VoiceHandle* voices_out);
+
 /* Voice handle <-> raw conditioning rows [frames][d_model]. */
 POCKET_TTS_API VoiceHandle pocket_tts_voice_from_embeddings(const float* embeddings, int frames, int d_model);
 POCKET_TTS_API int pocket_tts_voice_frames(VoiceHandle voice);

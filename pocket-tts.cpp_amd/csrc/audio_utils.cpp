@@ -4,6 +4,7 @@
 #include "pocket_tts/audio_utils.hpp"
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -143,16 +144,33 @@ std::vector<float> AudioUtils::resample(const std::vector<float>& input, int inp
     const double radius = A / fscale;
     const int in_n = static_cast<int>(input.size());
     std::vector<float> out(out_n);
+    // The tap weights of an output sample depend on its fractional position alone.  They are kept per distinct value of that
+    // fraction (compared bit for bit, so a reused weight is the very double the expression yields): when the rate ratio is a
+    // dyadic number (48 kHz or 96 kHz to 24 kHz: every fraction is 0) two sines per tap become two per file; for other ratios
+    // (44.1 kHz) the products i * step round differently for each i and nearly every sample computes its own.
+    struct Phase { uint64_t key; int lo, hi; bool used; std::vector<double> w; };
+    constexpr size_t kPhases = 256;
+    std::vector<Phase> phases(kPhases);
+    for (auto& p : phases) p.used = false;
     for (size_t i = 0; i < out_n; ++i) {
         const double src = i * step;
         const int center = static_cast<int>(std::floor(src));
         const double frac = src - center;
-        const int lo = static_cast<int>(std::ceil(-radius + frac)), hi = static_cast<int>(std::floor(radius + frac));
+        uint64_t key;
+        std::memcpy(&key, &frac, 8);
+        Phase& ph = phases[(key ^ (key >> 17) ^ (key >> 43)) % kPhases];
+        if (!ph.used || ph.key != key) {
+            ph.key = key; ph.used = true;
+            ph.lo = static_cast<int>(std::ceil(-radius + frac)); ph.hi = static_cast<int>(std::floor(radius + frac));
+            ph.w.resize(static_cast<size_t>(ph.hi - ph.lo + 1));
+            for (int j = ph.lo; j <= ph.hi; ++j) ph.w[static_cast<size_t>(j - ph.lo)] = lanczos((j - frac) * fscale, A);
+        }
         double acc = 0.0, wsum = 0.0;
-        for (int j = lo; j <= hi; ++j) {
+        const double* wp = ph.w.data() - ph.lo;
+        for (int j = ph.lo; j <= ph.hi; ++j) {
             const int idx = center + j;
             if (idx < 0 || idx >= in_n) continue;
-            const double w = lanczos((j - frac) * fscale, A);
+            const double w = wp[j];
             acc += input[idx] * w;
             wsum += w;
         }

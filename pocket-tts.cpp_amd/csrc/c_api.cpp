@@ -122,6 +122,21 @@ POCKET_TTS_API VoiceHandle pocket_tts_encode_voice(PocketTTSHandle handle, const
     }
 }
 
+POCKET_TTS_API int pocket_tts_encode_voices(PocketTTSHandle handle, int n, const char* const* audio_paths, VoiceHandle* voices_out) {
+    if (!handle || n < 0 || (n > 0 && (!audio_paths || !voices_out))) { set_error("Invalid parameters"); return -1; }
+    for (int i = 0; i < n; ++i) {
+        voices_out[i] = nullptr;
+        if (!audio_paths[i]) { set_error("Invalid audio path"); return -1; }
+    }
+    return guarded("Failed to encode voices: ", [&] {
+        auto* tts = tts_of(handle);
+        std::vector<std::string> paths(audio_paths, audio_paths + n);
+        auto emb = tts->encodeVoices(paths);
+        for (int i = 0; i < n; ++i) voices_out[i] = make_voice(std::move(emb[i]), tts->engine().spec().d_model);
+        return 0;
+    });
+}
+
 POCKET_TTS_API VoiceHandle pocket_tts_encode_voice_from_samples(PocketTTSHandle handle, const float* audio_data, int sample_count,
                                                                 int sample_rate) {
     if (!handle || !audio_data || sample_count <= 0) {

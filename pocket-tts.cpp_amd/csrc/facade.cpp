@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <iostream>
 #include <map>
 #include <mutex>
@@ -110,6 +111,75 @@ struct PocketTTS::Impl {
         return emb;
     }
 
+    // Many voice files at once (the voice-clone workload: a thousand reference clips): host threads decode, resample,
+    // attenuate and cut the files (src/audio_utils.cpp:45-159, 205-259; src/pocket_tts.cpp:253-259) while the GPU encodes the
+    // window of clips that is already prepared; results land in the path-keyed cache like single calls (:243-246, :294).
+    std::vector<std::vector<float>> encode_voice_paths(const std::vector<std::string>& paths) {
+        if (!config.loadVoiceEncoder) throw std::runtime_error("Voice encoder is disabled (loadVoiceEncoder=false).");
+        const size_t n = paths.size(), max_samples = static_cast<size_t>(AudioUtils::TARGET_SAMPLE_RATE) * 5;
+        std::vector<std::vector<float>> out(n), clips(n);
+        std::vector<char> cached(n, 0), ready(n, 0);
+        {
+            std::lock_guard<std::mutex> lk(cache_mu);
+            for (size_t i = 0; i < n; ++i) {
+                auto it = voice_cache.find(paths[i]);
+                if (it != voice_cache.end()) { out[i] = it->second; cached[i] = 1; }
+            }
+        }
+        std::mutex mu;
+        std::condition_variable cv;
+        std::atomic<size_t> next{0};
+        std::exception_ptr failed;
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t workers = std::min<size_t>({n, 16, hw});
+        std::vector<std::thread> pool;
+        for (size_t w = 0; w < workers; ++w)
+            pool.emplace_back([&] {
+                for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+                    std::exception_ptr err;
+                    if (!cached[i]) {
+                        try {
+                            clips[i] = AudioUtils::loadWav(paths[i], AudioUtils::TARGET_SAMPLE_RATE);
+                            if (clips[i].size() > max_samples) clips[i].resize(max_samples);
+                            if (clips[i].empty()) throw std::runtime_error("voice clip is empty: " + paths[i]);
+                        } catch (...) { err = std::current_exception(); }
+                    }
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (err && !failed) failed = err;
+                    ready[i] = 1;
+                    cv.notify_all();
+                }
+            });
+        const size_t window = 32;   // clips per encoder call; the engine stacks them 8 at a time over two buffer sets
+        std::exception_ptr enc_failed;
+        for (size_t first = 0; first < n && !enc_failed; first += window) {
+            const size_t last = std::min(n, first + window);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { for (size_t i = first; i < last; ++i) if (!ready[i]) return false; return true; });
+                if (failed) break;
+            }
+            std::vector<const float*> ptrs;
+            std::vector<int> lens;
+            std::vector<size_t> idx;
+            for (size_t i = first; i < last; ++i)
+                if (!cached[i]) { ptrs.push_back(clips[i].data()); lens.push_back(static_cast<int>(clips[i].size())); idx.push_back(i); }
+            if (ptrs.empty()) continue;
+            try {
+                std::vector<std::vector<float>> emb;
+                engine->encode_voice_batch(ptrs, lens, emb);
+                for (size_t k = 0; k < idx.size(); ++k) { out[idx[k]] = std::move(emb[k]); std::vector<float>().swap(clips[idx[k]]); }
+            } catch (...) { enc_failed = std::current_exception(); }
+        }
+        for (auto& t : pool) t.join();
+        if (failed) std::rethrow_exception(failed);
+        if (enc_failed) std::rethrow_exception(enc_failed);
+        std::lock_guard<std::mutex> lk(cache_mu);
+        for (size_t i = 0; i < n; ++i)
+            if (!cached[i]) voice_cache[paths[i]] = out[i];
+        return out;
+    }
+
     int frames_of(const std::vector<float>& emb, const std::vector<int64_t>& shape) const {
         const int D = engine->spec().d_model;
         if (shape.size() >= 2) {
@@ -159,6 +229,7 @@ const PocketTTSConfig& PocketTTS::config() const { return impl_->config; }
 std::vector<int64_t> PocketTTS::tokenize(const std::string& text) const { return impl_->tokenize(text); }
 
 std::vector<float> PocketTTS::encodeVoice(const std::string& audioPath) { return impl_->encode_voice_path(audioPath); }
+std::vector<std::vector<float>> PocketTTS::encodeVoices(const std::vector<std::string>& audioPaths) { return impl_->encode_voice_paths(audioPaths); }
 
 std::vector<float> PocketTTS::encodeVoiceFromSamples(const float* samples, int count, int sampleRate) {
     std::vector<float> audio(samples, samples + count);

@@ -47,7 +47,7 @@ DROP_IN_SYMBOLS = [
 ]
 EXT_SYMBOLS = [
     "pocket_tts_create_ex", "pocket_tts_dims", "pocket_tts_voice_from_embeddings", "pocket_tts_voice_frames",
-    "pocket_tts_voice_data", "pocket_tts_generate_batch", "pocket_tts_generate_ids", "pocket_tts_generate_ids_queued", "pocket_tts_streaming_ids",
+    "pocket_tts_voice_data", "pocket_tts_encode_voices", "pocket_tts_generate_batch", "pocket_tts_generate_ids", "pocket_tts_generate_ids_queued", "pocket_tts_streaming_ids",
     "pocket_tts_stage_ids", "pocket_tts_run_staged", "pocket_tts_fetch_staged",
     "pocket_tts_tokenize", "ptts_text_conditioner", "ptts_state_new", "ptts_state_free", "ptts_state_reset",
     "ptts_lm_prefill", "ptts_lm_step", "ptts_flow_euler", "ptts_flow_euler_noalloc", "ptts_flow_euler_noalloc_capacity", "ptts_mimi_decode", "ptts_mimi_encode", "ptts_mimi_encode_batch",
@@ -86,6 +86,7 @@ def load() -> C.CDLL:
     L.pocket_tts_dims.restype = ci; L.pocket_tts_dims.argtypes = [vp, C.POINTER(ci)]
     L.pocket_tts_voice_from_embeddings.restype = vp; L.pocket_tts_voice_from_embeddings.argtypes = [f32p, ci, ci]
     L.pocket_tts_voice_frames.restype = ci; L.pocket_tts_voice_frames.argtypes = [vp]
+    L.pocket_tts_encode_voices.restype = ci; L.pocket_tts_encode_voices.argtypes = [vp, ci, C.POINTER(cp), C.POINTER(vp)]
     L.pocket_tts_voice_data.restype = C.POINTER(C.c_float); L.pocket_tts_voice_data.argtypes = [vp]
     L.pocket_tts_tokenize.restype = ci; L.pocket_tts_tokenize.argtypes = [vp, cp, i64p, ci]
     L.pocket_tts_generate_batch.restype = ci
@@ -337,6 +338,20 @@ class Engine:
         op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
         rows = _check(self.L.ptts_mimi_encode_batch(self.h, cp, n, samples, op, cap), "mimi_encode_batch")
         return [o[:rows].copy() for o in outs]
+
+    def encode_voice_paths(self, paths: Sequence[str]) -> List[np.ndarray]:
+        """pocket_tts_encode_voices: one embedding [frames][d_model] per WAV file, files prepared on host threads while the
+        GPU encodes."""
+        n = len(paths)
+        pp_ = (C.c_char_p * n)(*[p.encode() for p in paths])
+        vo = (C.c_void_p * n)()
+        _check(self.L.pocket_tts_encode_voices(self.h, n, pp_, vo), "encode_voices")
+        out = []
+        for i in range(n):
+            nf = self.L.pocket_tts_voice_frames(vo[i])
+            out.append(np.ctypeslib.as_array(self.L.pocket_tts_voice_data(vo[i]), shape=(nf * self.d_model,)).reshape(nf, self.d_model).copy())
+            self.L.pocket_tts_free_voice(vo[i])
+        return out
 
     # ---- whole path ----
     def generate_ids(self, ids_list: Sequence[np.ndarray], voices: Sequence[np.ndarray],

@@ -42,6 +42,9 @@ timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/latency_probe.py --runs 20 > 
 timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/latency_probe.py --runs 20 --precision bf16 > "$OUT/${R}_latency_bf16.json"
 timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/latency_probe.py --runs 20 --precision int8 > "$OUT/${R}_latency_int8.json"
 timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/encode_bench.py > "$OUT/${R}_encode.json"
+timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/encode_bench.py --wavs 1024 > "$OUT/${R}_encode_wavs.json"
+timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/encode_bench.py --wavs 256 --wav-rate 48000 >> "$OUT/${R}_encode_wavs.json"
+timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/encode_bench.py --wavs 64 --wav-rate 44100 >> "$OUT/${R}_encode_wavs.json"
 rm -f gpurun_out/fullsize_parity.txt gpurun_out/table_stats.txt
 timeout -k 10 900 python3 -u -m pytest tests/test_gpu_fullsize.py tests/test_gpu_configs.py tests/test_gpu_table.py -x -q --timeout 300 --timeout-method thread > "$OUT/fullsize_run.log" 2>&1
 cp gpurun_out/fullsize_parity.txt "$OUT/${R}_fullsize_parity.txt"

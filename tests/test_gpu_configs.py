@@ -94,6 +94,69 @@ def test_voice_encoder_5s_clip_and_truncated_10s_input(env):
     eng.close()
 
 
+def _write_pcm16(path, x, rate, channels):
+    import wave
+    q = np.clip(np.round(x * 32767.0), -32768, 32767).astype("<i2")
+    if channels == 2:
+        q = np.stack([q, (q // 2).astype("<i2")], axis=1).reshape(-1)
+    with wave.open(path, "wb") as w:
+        w.setnchannels(channels)
+        w.setsampwidth(2)
+        w.setframerate(rate)
+        w.writeframes(q.tobytes())
+
+
+def test_many_voice_files_in_one_call(env, tmp_path):
+    """pocket_tts_encode_voices over ten files of three kinds (float32 24 kHz mono 10 s, PCM16 48 kHz stereo 7 s, PCM16 16 kHz
+    mono 3 s): each result equals the single-file path on the same file (decode, resample, attenuate, cut to 5 s, encode), one
+    of each kind equals the oracle's encoding of the prepared clip, a second call is served from the path cache, and a
+    missing file fails the whole call."""
+    lib, spec = env["lib"], env["spec"]
+    o = env["mod"].Oracle(env["path"])
+    paths = []
+    for i in range(10):
+        p = str(tmp_path / f"voice_{i}.wav")
+        kind = i % 3
+        if kind == 0:
+            lib.audio_save_wav(p, _clip(240000, 40 + i) * np.float32(2.0), 24000)
+        elif kind == 1:
+            n = 7 * 48000
+            t = np.arange(n) / 48000.0
+            _write_pcm16(p, 0.3 * np.sin(2 * np.pi * (150.0 + 20 * i) * t) + 0.1 * np.sin(2 * np.pi * 900.0 * t), 48000, 2)
+        else:
+            n = 3 * 16000
+            t = np.arange(n) / 16000.0
+            _write_pcm16(p, 0.5 * np.sin(2 * np.pi * (210.0 + 10 * i) * t) * np.exp(-t), 16000, 1)
+        paths.append(p)
+    eng = lib.Engine(env["path"], precision="fp32", temperature=0.0, lsd_steps=10, max_frames=4)
+    got = eng.encode_voice_paths(paths)
+    single = lib.Engine(env["path"], precision="fp32", temperature=0.0, lsd_steps=10, max_frames=4)
+    worst = worst_o = 0.0
+    for i, p in enumerate(paths):
+        clip = lib.audio_load_wav(p)[:120000]
+        assert got[i].shape == ((len(clip) + spec.frame_size - 1) // spec.frame_size, spec.d_model)
+        v = single.L.pocket_tts_encode_voice(single.h, p.encode())
+        assert v, lib.last_error()
+        nf = single.L.pocket_tts_voice_frames(v)
+        alone = np.ctypeslib.as_array(single.L.pocket_tts_voice_data(v), shape=(nf * spec.d_model,)).reshape(nf, spec.d_model).copy()
+        single.L.pocket_tts_free_voice(v)
+        assert alone.shape == got[i].shape
+        worst = max(worst, float(np.abs(got[i] - alone).max()) / max(float(np.abs(alone).max()), 1.0))
+        if i < 3:
+            want = o.mimi_encode(clip)
+            worst_o = max(worst_o, float(np.abs(got[i] - want).max()) / max(float(np.abs(want).max()), 1.0))
+    _note(f"fp32 full size voice encoder, 10 files of 3 kinds in one call: against the single-file call {worst:.3e}, against the oracle {worst_o:.3e} "
+          f"(max-abs relative to the largest output)")
+    assert worst <= 1e-3 and worst_o <= 1e-3
+    again = eng.encode_voice_paths(paths[::-1])
+    for i in range(10):
+        assert np.array_equal(again[9 - i], got[i])
+    with pytest.raises(lib.PttsError):
+        eng.encode_voice_paths(paths[:2] + [str(tmp_path / "missing.wav")])
+    eng.close()
+    single.close()
+
+
 def _replay_selected(o, ids, voice, gpu_latents, lsd_steps, check):
     """Oracle LM over every frame on the GPU's own history; flow head only for the frames in `check`.
     Returns {frame: (oracle latent, oracle eos)}."""
