@@ -504,8 +504,11 @@ static void flow_ring_shape(int B, int blocks, int budget, int& rpg, int& replic
     rpg = 4;   // one row per wave
     const int ngroups = (B + rpg - 1) / rpg;
     // measured at B = 64 beside the decoder stream with 8 slices: 2 replicas 0.65 ms per flow phase, 3 0.49, 4 0.43 (launch
-    // chain 0.54); the same 192 workgroups make 8 replicas of 4 slices
-    replicas = G == 8 ? 4 : 8;
+    // chain 0.54).  With 4 slices 192 workgroups would make 8 replicas, and alone on the chip that is the fastest form; beside
+    // the decoder stream, which is confined to 128 of the 256 CUs, 4 or 5 replicas (96 / 120 workgroups: every one finds a CU
+    // the decoder never uses, and a workgroup of this kernel needs a CU's whole register file) are faster than 6 to 8, whose
+    // launch waits for decoder workgroups to drain: 6400 against 6250 RTFx
+    replicas = G == 8 ? 4 : 5;
     if (const char* e = std::getenv("FLOW_RING_REPLICAS")) replicas = std::atoi(e);
     const int max_rep = budget / (blocks * G);     // every workgroup must be resident at once; leave CUs for other streams
     if (replicas > max_rep) replicas = max_rep;
