@@ -275,7 +275,6 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
 
     auto decode_chunk = [&](PartRun& r, int f0, int n) {
         Batch& b = *r.b;
-        if (std::getenv("PTTS_EXPERIMENT_SKIP_DECODE")) return;
         if (b.dec_st != b.st) {
             PTTS_HIP(hipEventRecord(b.ready, b.st));
             PTTS_HIP(hipStreamWaitEvent(b.dec_st, b.ready, 0));
@@ -352,7 +351,7 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
                     PTTS_HIP(hipEventRecord(dec_done_, b.dec_st));
                     PTTS_HIP(hipStreamWaitEvent(b.st, dec_done_, 0));
                 }
-                for (int f0 = r.decoded; f0 < fmax && !std::getenv("PTTS_EXPERIMENT_SKIP_DECODE"); f0 += kDecChunk) {
+                for (int f0 = r.decoded; f0 < fmax; f0 += kDecChunk) {
                     const int n = std::min(kDecChunk, fmax - f0);
                     mimi_decode_dev(b, b.latents.f() + static_cast<size_t>(f0) * L, static_cast<long long>(b.lat_frames) * L, n,
                                     b.audio_all.f() + static_cast<size_t>(f0) * fs, static_cast<long long>(opt_.max_frames) * fs, b.st);
