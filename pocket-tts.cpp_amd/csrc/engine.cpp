@@ -286,6 +286,43 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
         flow_tabs.ln_g.push_back(f(p + "ln.g"));
         flow_tabs.ln_b.push_back(f(p + "ln.b"));
     }
+    // Matrix planes of the persistent flow head.  bf16 engine: the fragment-major matrices as they are.  float engine: every
+    // matrix as two bf16 planes, hi = bf16(W) and lo = bf16(W - hi), multiplied with two-term activations on three bf16
+    // MFMAs per tile (about 16 mantissa bits; POCKET_TTS_FLOW_F32_CHAIN=1 keeps the float launch chain instead).
+    if (flow_wtype == W_BF16 && flow_block_wtype == W_BF16) {
+        flow_tabs.r_in = flow_in_packed; flow_tabs.r_out = flow_out_packed;
+        flow_tabs.r_fc1 = flow_tabs.w_fc1; flow_tabs.r_fc2 = flow_tabs.w_fc2;
+    } else if (flow_wtype == W_F32 && C == 512 && s.latent == 32 && !std::getenv("POCKET_TTS_FLOW_F32_CHAIN")) {
+        auto planes = [&](const std::string& name, const void*& hi_dev, const void*& lo_dev) {
+            const HostTensor& t = pack.get(name);
+            const size_t el = t.numel();
+            std::vector<float> hi(el), lo(el);
+            for (size_t i = 0; i < el; ++i) {
+                uint32_t u; std::memcpy(&u, &t.data[i], 4);
+                if ((u & 0x7f800000u) != 0x7f800000u) u += 0x7fffu + ((u >> 16) & 1u);
+                u &= 0xffff0000u;
+                std::memcpy(&hi[i], &u, 4);
+                lo[i] = t.data[i] - hi[i];
+            }
+            for (int k = 0; k < 2; ++k) {
+                auto bytes = pack_flow_weight(k ? lo.data() : hi.data(), static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), W_BF16);
+                extra_.emplace_back(bytes.size());
+                sync_copy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice);
+                (k ? lo_dev : hi_dev) = extra_.back().p;
+            }
+        };
+        planes("flow.in_proj.w", flow_tabs.r_in, flow_tabs.r_in_lo);
+        planes("flow.final.lin.w", flow_tabs.r_out, flow_tabs.r_out_lo);
+        for (int i = 0; i < nb; ++i) {
+            const std::string p = "flow.b" + std::to_string(i) + ".";
+            const void *h1, *l1, *h2, *l2;
+            planes(p + "fc1.w", h1, l1);
+            planes(p + "fc2.w", h2, l2);
+            flow_tabs.r_fc1.push_back(h1); flow_tabs.r_fc1_lo.push_back(l1);
+            flow_tabs.r_fc2.push_back(h2); flow_tabs.r_fc2_lo.push_back(l2);
+        }
+        flow_ring_split = true;
+    }
 }
 
 void DevWeight::bind(GemmArgs& g, int M) const {
@@ -1081,7 +1118,7 @@ void Engine::flow_scratch_layout(int rows, size_t off[6]) const {
 }
 
 void Engine::check_flow_ring(const unsigned* ctl, int rows) {
-    if (!ctl || model_->flow_wtype != W_BF16 || spec().flow_dim != 512) return;
+    if (!ctl || !(model_->flow_wtype == W_BF16 || model_->flow_ring_split) || spec().flow_dim != 512) return;
     unsigned err = 0;
     sync_copy(&err, ctl + flow_ring_err_word(rows, spec().flow_blocks), 4, hipMemcpyDeviceToHost);
     if (err) {
@@ -1111,7 +1148,7 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
     // the persistent head's counters start every call at zero; this launch (two boundaries ahead of the head) clears them
     FlowHeadArgs probe;
     probe.C = C; probe.L = s.latent; probe.blocks = s.flow_blocks; probe.steps = N; probe.B = B; probe.wtype = model_->flow_wtype;
-    probe.block_wtype = model_->flow_block_wtype; probe.ring_ctl = fs.ctl; probe.ring_wg_budget = 224 / std::max(lanes_, 1);
+    probe.block_wtype = model_->flow_block_wtype; probe.ring_split = model_->flow_ring_split; probe.ring_ctl = fs.ctl; probe.ring_wg_budget = 224 / std::max(lanes_, 1);
     const bool ring = owns_ring_ && fs.ctl && flow_ring_supported(probe);
     const int cw = static_cast<int>(flow_ring_counter_word());
     launch_flow_mod_input(flow_te_.f(), fs.cemb, cs, hd_.flow_cond_b, fs.ymod, N, B, C, st, frame ? &pub : nullptr, ring ? fs.ctl + cw : nullptr,
@@ -1135,6 +1172,7 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
     fa.host_tabs = &model_->flow_tabs; fa.workspace = fs.ws; fa.wtype = model_->flow_wtype; fa.eps = s.flow_eps;
     fa.block_wtype = model_->flow_block_wtype;
     fa.ring_ctl = ring ? fs.ctl : nullptr;
+    fa.ring_split = model_->flow_ring_split;
     fa.ring_wg_budget = probe.ring_wg_budget;   // concurrent lanes share the chip: every ring in flight must be fully resident
     fa.x0_step = x0_step; fa.x0_step_stride = x0_step_stride; fa.probe_a = probe_a; fa.probe_b = probe_b;
     if (frame) {   // the counter was advanced when the EOS logits were published: the frame index is *step - 1

@@ -81,6 +81,7 @@ public:
     struct PackedLayer { const void *qkv, *out, *ff1, *ff2; const float *s_qkv = nullptr, *s_out = nullptr, *s_ff1 = nullptr, *s_ff2 = nullptr; };
     int lm_wtype = W_F32;        // weight type of lm_packed (W_I8 in int8 mode)
     int flow_block_wtype = W_F32;
+    bool flow_ring_split = false;   // float engine: flow_tabs carries two-term bf16 planes for the persistent flow head
     std::vector<PackedLayer> lm_packed;
     const void* enc_ds_packed = nullptr;   // voice encoder's down-sampling matrix, fragment-major f32 (K-slice product of short clips)
     const void* flow_cond_packed = nullptr;

@@ -295,7 +295,7 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
         times_.flow_ms += fl; times_.flow_calls++;
         FlowHeadArgs fa;
         fa.C = spec().flow_dim; fa.L = spec().latent; fa.B = b.Bw; fa.steps = opt_.lsd_steps; fa.blocks = spec().flow_blocks;
-        fa.wtype = model_->flow_wtype; fa.block_wtype = model_->flow_block_wtype;
+        fa.wtype = model_->flow_wtype; fa.block_wtype = model_->flow_block_wtype; fa.ring_split = model_->flow_ring_split;
         fa.ring_ctl = owns_ring_ ? b.flow_ctl.as<unsigned>() : nullptr; fa.ring_wg_budget = 224 / std::max(lanes_, 1);
         times_.head_ms += hd; times_.head_calls += flow_head_launch_count(fa);
     };

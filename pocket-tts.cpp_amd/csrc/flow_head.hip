@@ -885,7 +885,7 @@ static void flow_head_shape(int C, int B, bool bf, int& G, int& rpg) {
 
 size_t flow_head_workspace_bytes(int B, int C, int wtype, int blocks) {
     const size_t chain = ((size_t)2 * B * C + (size_t)2 * kMaxFlowSplit * B * C + (size_t)2 * B * 32) * sizeof(float);   // h x2, partials x2, x x2
-    const size_t ring = (wtype == W_BF16 && C == 512) ? flow_ring_workspace_bytes(B, blocks) : 0;   // the persistent form keeps one set per block
+    const size_t ring = C == 512 ? flow_ring_workspace_bytes(B, blocks) : 0;   // the persistent form keeps one set per block
     return chain > ring ? chain : ring;
 }
 
@@ -991,7 +991,7 @@ static void prepare_chain() {
 }
 void flow_head_prepare(int C, int wtype) {
     const bool bf = wtype == W_BF16;
-    if (bf && C == 512) flow_ring_prepare();
+    if (C == 512) flow_ring_prepare();
     switch (C) {
         case 128: bf ? prepare_chain<__bf16, 128, true>() : prepare_chain<float, 128, false>(); break;
         case 256: bf ? prepare_chain<__bf16, 256, true>() : prepare_chain<float, 256, false>(); break;

@@ -8,7 +8,8 @@
 //
 //   grid = replicas x blocks x G workgroups of 256 threads (one wave per SIMD, so each wave may hold up to 512
 //   registers), one per CU.  Workgroup (rep, blk, g) owns, for residual block blk, the column slice g of fc1 and the
-//   matching K-slice of fc2 (64 KB + 64 KB of bf16 at flow_dim 512, G = 8): 128 registers per lane, loaded once.
+//   matching K-slice of fc2 (64 KB + 64 KB of bf16 at flow_dim 512, G = 8: 128 registers per lane; twice that with G = 4,
+//   the default, or with two-term matrices), loaded once.
 //   Rows travel in groups of RPG utterances; replica rep serves the row groups q = rep, rep + replicas, ...  A "visit" is one row group passing one workgroup: rebuild the residual
 //   stream from the previous block's G partial slabs, LayerNorm + adaLN modulation, fc1 slice, SiLU, fc2 K-slice,
 //   publish the partial slab.  The workgroups of block 0 also run, for the row group they are about to start, the
@@ -23,8 +24,12 @@
 // zeroed by an earlier kernel of the same frame.  Every spin is bounded: a workgroup that gives up raises the error
 // word, which every other spin also watches, and the launch drains.
 //
-// Sums are formed in a fixed order (partials 0..G-1), so results are bitwise reproducible and equal to the launch
-// chain's G = 8 variant.
+// Sums are formed in a fixed order (partials 0..G-1), so results are bitwise reproducible (and, with G = 8 and bf16
+// matrices, equal to the launch chain's 8-slice variant).
+//
+// The float engine uses the same kernel: its matrices come as two bf16 planes each (W = hi + lo) and every tile takes a
+// third MFMA (hi_a * lo_w beside hi_a * hi_w and lo_a * hi_w), which carries weights and activations to about 16 mantissa
+// bits at bf16 MFMA speed; the float launch chain it replaces runs f32 MFMAs at a sixteenth of that rate.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -82,9 +87,11 @@ template <int RPG>
 __device__ __forceinline__ bf16x8 afrag(const __bf16* A, int lda, int k0, int lane) {
     return *(const bf16x8*)(A + (lane & (RPG - 1)) * lda + k0 + 8 * (lane >> 4));
 }
-// acc += (hi + lo) * fragment
-__device__ __forceinline__ void mma2(const bf16x8 hi, const bf16x8 lo, const uint4 w, f32x4& acc) {
+// acc += (hi + lo) * fragment; with two-term weights (WS) also hi * (the fragment's second term)
+template <bool WS>
+__device__ __forceinline__ void mma2(const bf16x8 hi, const bf16x8 lo, const uint4 w, const uint4 wl, f32x4& acc) {
     const bf16x8 b8 = __builtin_bit_cast(bf16x8, w);
+    if constexpr (WS) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, __builtin_bit_cast(bf16x8, wl), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, b8, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, b8, acc, 0, 0, 0);
 }
@@ -139,7 +146,9 @@ struct FlowRingArgs {
     const float* mods;
     int B, blocks, steps, mod_width, replicas, ngroups;
     const void* w_in; const float* b_in; const void* w_out; const float* b_out;
+    const void* w_in_lo; const void* w_out_lo;   // second terms of two-term matrices (float engine), else null
     const void* w1[kFlowRingMaxBlocks]; const void* w2[kFlowRingMaxBlocks];
+    const void* w1l[kFlowRingMaxBlocks]; const void* w2l[kFlowRingMaxBlocks];
     const float* b1[kFlowRingMaxBlocks]; const float* b2[kFlowRingMaxBlocks];
     const float* ln_g[kFlowRingMaxBlocks]; const float* ln_b[kFlowRingMaxBlocks];
     float* ws; unsigned ws_bytes;        // hstage [blocks][B][C] then part [blocks][G][B][C], f32
@@ -150,8 +159,9 @@ struct FlowRingArgs {
 
 // RPG: utterance rows per row group (one wave per row in the element-wise phases).  G: workgroups per residual block
 // (column slices of fc1 = K-slices of fc2): 4 keeps 256 registers of matrices per lane and halves the partial slabs a
-// visit reads and the number of consumers that read them; 8 keeps 128.
-template <int RPG, int G>
+// visit reads and the number of consumers that read them; 8 keeps 128.  WS: every matrix comes as two bf16 terms (the float
+// engine's matrices to ~16 mantissa bits) and every tile takes a third MFMA; the register budget then allows G = 8 only.
+template <int RPG, int G, bool WS>
 __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
     constexpr int NT1 = NT / G, NW1 = NT1 / kWaves, KS2 = KS / G, CS = C / G, LDA2 = lda2_of(G);
     static_assert(NW1 >= 1 && NW1 * kWaves == NT1 && KS2 * G == KS, "flow ring: slices must divide the tiles of fc1 and the k-steps of fc2");
@@ -168,6 +178,8 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
     int* sflag = (int*)(xkeep + ((a.ngroups + a.replicas - 1) / a.replicas) * RPG * L);
     uint4* win_l = (uint4*)(sflag + 4);                       // block 0: input projection [NT][64 lanes] fragments, then output projection [NTL * KS][64]
     uint4* wout_l = win_l + NT * 64;
+    uint4* win_lo = wout_l + NTL * KS * 64;                   // WS: the second terms, same shapes
+    uint4* wout_lo = win_lo + NT * 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = blockIdx.x;
@@ -183,6 +195,23 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
     // ---- this workgroup's matrices, once: fc1 tile `wave` of slice g over all of K; fc2 tiles 8 * wave .. 8 * wave + 7
     // (128 consecutive columns: four whole 128-byte lines of every output row) for K-slice g
     uint4 wf1[NW1][KS], wf2[T2][KS2];
+    uint4 wf1l[WS ? NW1 : 1][WS ? KS : 1], wf2l[WS ? T2 : 1][WS ? KS2 : 1];
+    if constexpr (WS) {
+#pragma unroll
+        for (int t = 0; t < NW1; ++t) {
+            const uint4* w1p = (const uint4*)a.w1l[blk] + ((long long)(g * NT1 + wave * NW1 + t) * KS) * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wf1l[t][ks] = w1p[ks * 64];
+        }
+        const uint4* w2p = (const uint4*)a.w2l[blk] + (long long)(g * KS2) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < T2; ++i) {
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) wf2l[i][ks] = w2p[((long long)(T2 * wave + i) * KS + ks) * 64];
+        }
+    } else {
+        wf1l[0][0] = make_uint4(0u, 0u, 0u, 0u); wf2l[0][0] = make_uint4(0u, 0u, 0u, 0u);
+    }
     {
 #pragma unroll
         for (int t = 0; t < NW1; ++t) {
@@ -207,6 +236,10 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
     if (first_blk) {
         for (int i = tid; i < NT * 64; i += kThreads) win_l[i] = ((const uint4*)a.w_in)[i];
         for (int i = tid; i < NTL * KS * 64; i += kThreads) wout_l[i] = ((const uint4*)a.w_out)[i];
+        if constexpr (WS) {
+            for (int i = tid; i < NT * 64; i += kThreads) win_lo[i] = ((const uint4*)a.w_in_lo)[i];
+            for (int i = tid; i < NTL * KS * 64; i += kThreads) wout_lo[i] = ((const uint4*)a.w_out_lo)[i];
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i) bin[i] = a.b_in[(wave + kWaves * i) * 16 + ccol];
         __syncthreads();
@@ -270,7 +303,10 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
 #pragma unroll
             for (int ks = 0; ks < KSP; ++ks) { fh[ks] = afrag<RPG>(A0, LDA, (kpo * KSP + ks) * KSTEP, lane); fl[ks] = afrag<RPG>(A1, LDA, (kpo * KSP + ks) * KSTEP, lane); }
 #pragma unroll
-            for (int ks = 0; ks < KSP; ++ks) mma2(fh[ks], fl[ks], wout_l[(to * KS + kpo * KSP + ks) * 64 + lane], acco);
+            for (int ks = 0; ks < KSP; ++ks) {
+                const int wi = (to * KS + kpo * KSP + ks) * 64 + lane;
+                mma2<WS>(fh[ks], fl[ks], wout_l[wi], WS ? wout_lo[wi] : wout_l[wi], acco);
+            }
         }
         *(f32x4*)(hbuf + wave * 256 + lane * 4) = acco;
         __syncthreads();
@@ -345,7 +381,8 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
                     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                    mma2(xh, xl, win_l[(wave + kWaves * i) * 64 + lane], acc);
+                    const int wi = (wave + kWaves * i) * 64 + lane;
+                    mma2<WS>(xh, xl, win_l[wi], WS ? win_lo[wi] : win_l[wi], acc);
                     const int c = (wave + kWaves * i) * 16 + ccol;
                     hbuf[lq * C + c] = own_row(acc, lq) + bin[i];
                 }
@@ -416,7 +453,7 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
 #pragma unroll
                     for (int k = 0; k < GK; ++k) {
 #pragma unroll
-                        for (int t = 0; t < NW1; ++t) mma2(fh[n & 1][k], fl[n & 1][k], wf1[t][n * GK + k], acc[t]);
+                        for (int t = 0; t < NW1; ++t) mma2<WS>(fh[n & 1][k], fl[n & 1][k], wf1[t][n * GK + k], wf1l[WS ? t : 0][WS ? n * GK + k : 0], acc[t]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -439,7 +476,7 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
                 for (int i = 0; i < T2; ++i) {
                     acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int ks = 0; ks < KS2; ++ks) mma2(sh_[ks], sl_[ks], wf2[i][ks], acc2[i]);
+                    for (int ks = 0; ks < KS2; ++ks) mma2<WS>(sh_[ks], sl_[ks], wf2[i][ks], wf2l[WS ? i : 0][WS ? ks : 0], acc2[i]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -483,24 +520,26 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
 
 // ------------------------------------------------------------------------------------------------ host side
 
-// Workgroups per residual block: 4 by default, FLOW_RING_SLICES=8 selects the earlier form.
-static int ring_slices() {
+// Workgroups per residual block: 4 by default, FLOW_RING_SLICES=8 selects the earlier form; two-term matrices need 8.
+static int ring_slices(bool split) {
     static const int g = [] { const char* e = std::getenv("FLOW_RING_SLICES"); return e && std::atoi(e) == 8 ? 8 : 4; }();
-    return g;
+    return split ? 8 : g;
 }
 
 bool flow_ring_supported(const FlowHeadArgs& a) {
     if (std::getenv("FLOW_HEAD_NO_RING")) return false;
-    const int G = ring_slices();
     const int bw = a.block_wtype < 0 ? a.wtype : a.block_wtype;
-    return a.C == C && a.L == L && a.wtype == W_BF16 && bw == W_BF16 && a.blocks >= 2 && a.blocks <= kFlowRingMaxBlocks && a.steps >= 1 &&
+    const bool split = a.wtype == W_F32 && bw == W_F32 && a.ring_split;
+    if (!split && !(a.wtype == W_BF16 && bw == W_BF16)) return false;
+    const int G = ring_slices(split);
+    return a.C == C && a.L == L && a.blocks >= 2 && a.blocks <= kFlowRingMaxBlocks && a.steps >= 1 &&
            a.ring_ctl != nullptr && a.B >= 1 && a.ring_wg_budget >= a.blocks * G;
 }
 
 // Row-group height and replica count for B rows.  More replicas shorten each workgroup's queue of row groups; the
 // chain of one row group (steps * blocks hand-offs) is the floor.  FLOW_RING_REPLICAS overrides.
-static void flow_ring_shape(int B, int blocks, int budget, int& rpg, int& replicas) {
-    const int G = ring_slices();
+static void flow_ring_shape(int B, int blocks, int budget, bool split, int& rpg, int& replicas) {
+    const int G = ring_slices(split);
     rpg = 4;   // one row per wave
     const int ngroups = (B + rpg - 1) / rpg;
     // measured at B = 64 beside the decoder stream with 8 slices: 2 replicas 0.65 ms per flow phase, 3 0.49, 4 0.43 (launch
@@ -528,11 +567,11 @@ size_t flow_ring_ctl_bytes(int B, int blocks) {
 size_t flow_ring_err_word(int, int) { return 0; }
 size_t flow_ring_counter_word() { return kCtlStride; }
 
-static size_t ring_smem(int rpg, int ngroups, int replicas) {
+static size_t ring_smem(int rpg, int ngroups, int replicas, bool split) {
     const int local = (ngroups + replicas - 1) / replicas;
-    const int LDA2 = lda2_of(ring_slices());
+    const int LDA2 = lda2_of(ring_slices(split));
     return (size_t)rpg * C * 4 + (size_t)2 * rpg * (LDA + LDA2 + LDX) * 2 + (size_t)kWaves * rpg * kTw * 4 + (size_t)local * rpg * L * 4 + 16 +
-           (size_t)(NT + NTL * KS) * 64 * 16;
+           (size_t)(NT + NTL * KS) * 64 * 16 * (split ? 2 : 1);
 }
 
 static void ring_lds_limit(const void* kernel) {
@@ -545,8 +584,9 @@ static void ring_lds_limit(const void* kernel) {
 }
 
 void flow_ring_prepare() {
-    if (ring_slices() == 8) ring_lds_limit((const void*)flow_ring_kernel<4, 8>);
-    else ring_lds_limit((const void*)flow_ring_kernel<4, 4>);
+    ring_lds_limit((const void*)flow_ring_kernel<4, 8, false>);
+    ring_lds_limit((const void*)flow_ring_kernel<4, 4, false>);
+    ring_lds_limit((const void*)flow_ring_kernel<4, 8, true>);
 }
 
 // The caller has zeroed a.ring_ctl (flow_ring_ctl_bytes) earlier on the same stream.
@@ -554,16 +594,22 @@ void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s) {
     if (!flow_ring_supported(a)) throw std::runtime_error("flow ring: unsupported shape");
     if (a.x_out == a.x0) throw std::runtime_error("flow ring: x_out must not alias x0");
     int rpg = 4, replicas = 1;
-    flow_ring_shape(a.B, a.blocks, a.ring_wg_budget, rpg, replicas);
+    const bool split = a.wtype == W_F32;
+    flow_ring_shape(a.B, a.blocks, a.ring_wg_budget, split, rpg, replicas);
     FlowRingArgs r{};
     r.x0 = a.x0; r.x0_stride = a.x0_stride; r.x0_step = a.x0_step; r.x0_step_stride = a.x0_step_stride; r.x0_step_bias = a.x0_step_bias; r.step_ring = a.step_ring;
     r.x_out = a.x_out; r.latents = a.latents; r.max_frames = a.max_frames;
     r.mods = a.mods; r.B = a.B; r.blocks = a.blocks; r.steps = a.steps; r.mod_width = a.mod_width;
     r.replicas = replicas; r.ngroups = (a.B + rpg - 1) / rpg;
-    r.w_in = a.w_in; r.b_in = a.b_in; r.w_out = a.w_out; r.b_out = a.b_out;
     const FlowHostTabs& t = *a.host_tabs;
+    if (!t.r_in || !t.r_out || (int)t.r_fc1.size() < a.blocks || (int)t.r_fc2.size() < a.blocks) throw std::runtime_error("flow ring: matrix planes missing");
+    if (split && (!t.r_in_lo || !t.r_out_lo || (int)t.r_fc1_lo.size() < a.blocks || (int)t.r_fc2_lo.size() < a.blocks))
+        throw std::runtime_error("flow ring: second matrix planes missing");
+    r.w_in = t.r_in; r.b_in = a.b_in; r.w_out = t.r_out; r.b_out = a.b_out;
+    r.w_in_lo = split ? t.r_in_lo : nullptr; r.w_out_lo = split ? t.r_out_lo : nullptr;
     for (int i = 0; i < a.blocks; ++i) {
-        r.w1[i] = t.w_fc1[i]; r.w2[i] = t.w_fc2[i]; r.b1[i] = t.b_fc1[i]; r.b2[i] = t.b_fc2[i]; r.ln_g[i] = t.ln_g[i]; r.ln_b[i] = t.ln_b[i];
+        r.w1[i] = t.r_fc1[i]; r.w2[i] = t.r_fc2[i]; r.b1[i] = t.b_fc1[i]; r.b2[i] = t.b_fc2[i]; r.ln_g[i] = t.ln_g[i]; r.ln_b[i] = t.ln_b[i];
+        r.w1l[i] = split ? t.r_fc1_lo[i] : nullptr; r.w2l[i] = split ? t.r_fc2_lo[i] : nullptr;
     }
     r.ws = a.workspace;
     const size_t wsb = flow_ring_workspace_bytes(a.B, a.blocks);
@@ -572,13 +618,14 @@ void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s) {
     r.ctl = a.ring_ctl;
     r.eps = a.eps; r.dt = 1.0f / (float)a.steps;
     r.stamps = a.cycle_probe;
-    const size_t smem = ring_smem(rpg, r.ngroups, replicas);
+    const size_t smem = ring_smem(rpg, r.ngroups, replicas, split);
     if (smem > 160 * 1024) throw std::runtime_error("flow ring: LDS request too large");
-    const int G = ring_slices();
+    const int G = ring_slices(split);
     const int grid = replicas * a.blocks * G;
     if (a.probe_a) (void)hipEventRecord(a.probe_a, s);
-    if (G == 8) hipLaunchKernelGGL((flow_ring_kernel<4, 8>), dim3(grid), dim3(kThreads), smem, s, r);
-    else hipLaunchKernelGGL((flow_ring_kernel<4, 4>), dim3(grid), dim3(kThreads), smem, s, r);
+    if (split) hipLaunchKernelGGL((flow_ring_kernel<4, 8, true>), dim3(grid), dim3(kThreads), smem, s, r);
+    else if (G == 8) hipLaunchKernelGGL((flow_ring_kernel<4, 8, false>), dim3(grid), dim3(kThreads), smem, s, r);
+    else hipLaunchKernelGGL((flow_ring_kernel<4, 4, false>), dim3(grid), dim3(kThreads), smem, s, r);
     if (a.probe_b) (void)hipEventRecord(a.probe_b, s);
 }
 

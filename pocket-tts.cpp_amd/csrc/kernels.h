@@ -186,6 +186,11 @@ struct FlowHostTabs {   // host arrays of per-block device pointers
     std::vector<const void*> w_fc1, w_fc2;           // pack_flow_weight (or pack_q8_weight) layout, [C][C]
     std::vector<const float*> b_fc1, b_fc2, ln_g, ln_b;
     std::vector<const float*> s_fc1, s_fc2;          // int8 blocks: per-output-column weight scales
+    // Matrices of the persistent form as bf16 fragment-major planes.  bf16 engine: the matrices above, no second plane.
+    // float engine: every matrix as two planes, W = hi + lo (lo = bf16(W - hi)), which the kernel multiplies with activations
+    // split the same way on three bf16 MFMAs per tile: float-grade products at bf16 MFMA speed.
+    std::vector<const void*> r_fc1, r_fc2, r_fc1_lo, r_fc2_lo;
+    const void *r_in = nullptr, *r_out = nullptr, *r_in_lo = nullptr, *r_out_lo = nullptr;
 };
 struct FlowHeadArgs {
     const float* x0 = nullptr;    // start points, row b at x0 + b * x0_stride (+ *x0_step * x0_step_stride if x0_step is set)
@@ -209,6 +214,7 @@ struct FlowHeadArgs {
     // Control words of the persistent form (flow_ring.hip): flow_ring_ctl_bytes(B, blocks) bytes that an earlier kernel on the
     // same stream has zeroed for this call.  Null: the launch chain is used.
     unsigned* ring_ctl = nullptr;
+    bool ring_split = false;     // float engine: host_tabs carries two-term bf16 planes of every matrix for the persistent form
     int ring_wg_budget = 224;    // workgroups the persistent form may occupy (all must be resident at once; other rings in flight share the chip)
 };
 void launch_flow_head(const FlowHeadArgs& a, hipStream_t s);

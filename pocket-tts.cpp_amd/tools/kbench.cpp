@@ -154,6 +154,7 @@ static void bench_flow(int B) {
     a.B = B; a.L = L; a.C = C; a.blocks = nb; a.steps = steps; a.mod_width = mw;
     a.w_in = packed_weight(C, L, W_T); a.b_in = (const float*)dalloc(C * 4);
     a.w_out = packed_weight(L, C, W_T); a.b_out = (const float*)dalloc(L * 4);
+    if (W_T == W_BF16) { tabs.r_fc1 = tabs.w_fc1; tabs.r_fc2 = tabs.w_fc2; tabs.r_in = a.w_in; tabs.r_out = a.w_out; }   // the persistent form's planes
     a.host_tabs = &tabs; a.workspace = (float*)dalloc(flow_head_workspace_bytes(B, C, W_T, nb), 0); a.wtype = W_T;
     flow_head_prepare(C, W_T);
     if (std::getenv("KB_FLOW_RING")) {
