@@ -289,7 +289,7 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     // Matrix planes of the persistent flow head.  bf16 engine: the fragment-major matrices as they are.  float engine: every
     // matrix as two bf16 planes, hi = bf16(W) and lo = bf16(W - hi), multiplied with two-term activations on three bf16
     // MFMAs per tile (about 16 mantissa bits; POCKET_TTS_FLOW_F32_CHAIN=1 keeps the float launch chain instead).
-    if (flow_wtype == W_BF16 && flow_block_wtype == W_BF16) {
+    if (flow_wtype == W_BF16) {   // bf16 or int8 blocks (the int8 form keeps its scales in s_fc1 / s_fc2)
         flow_tabs.r_in = flow_in_packed; flow_tabs.r_out = flow_out_packed;
         flow_tabs.r_fc1 = flow_tabs.w_fc1; flow_tabs.r_fc2 = flow_tabs.w_fc2;
     } else if (flow_wtype == W_F32 && C == 512 && s.latent == 32 && !std::getenv("POCKET_TTS_FLOW_F32_CHAIN")) {

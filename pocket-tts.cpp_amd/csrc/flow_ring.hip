@@ -117,6 +117,30 @@ __device__ __forceinline__ void put4(__bf16* A0, __bf16* A1, int idx, const floa
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
 
+// ---- int8 blocks (the int8 engine): the arithmetic of flow_block_q8_kernel in flow_head.hip.  A matrix input is quantised
+// per row and per block of 64 consecutive k: s = max|a|, q = rint(a * 127 / s), d = s / 127;
+// y[n] = (sum over blocks of (float)isum * d) * wscale[n] + bias[n].
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__device__ __forceinline__ unsigned q8_pack4(const float4 v, float inv) {
+    const int q0 = (int)rintf(v.x * inv), q1 = (int)rintf(v.y * inv), q2 = (int)rintf(v.z * inv), q3 = (int)rintf(v.w * inv);
+    return (unsigned)(q0 & 0xff) | ((unsigned)(q1 & 0xff) << 8) | ((unsigned)(q2 & 0xff) << 16) | ((unsigned)(q3 & 0xff) << 24);
+}
+// maximum of |v| over the 16 consecutive lanes that hold one 64-wide block (one float4 each)
+__device__ __forceinline__ float q8_absmax16(const float4 v) {
+    float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, true)));
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, true)));
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x141, 0xF, 0xF, true)));
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x140, 0xF, 0xF, true)));
+    return m;
+}
+__device__ __forceinline__ int own_row_i(const i32x4 acc, int q) { return q == 0 ? acc[0] : q == 1 ? acc[1] : q == 2 ? acc[2] : acc[3]; }
+__device__ __forceinline__ float silu_exact(float v) { return v / (1.0f + expf(-v)); }
+constexpr int KSQ = C / 64, LDQ = C + 16;     // int8 k-steps of a full row; row pitch of the int8 A plane (bytes)
+constexpr size_t q8_lds_bytes(int g) {         // Aq, dA, Sf, Sq, dS for 4 rows, rounded to 16 bytes
+    return ((size_t)4 * LDQ + (size_t)KSQ * 4 * 4 + (size_t)4 * (C / g) * 4 + (size_t)4 * (C / g + 16) + (size_t)(KSQ / g) * 4 * 4 + 15) / 16 * 16;
+}
+
 // handed-off bytes: write-through stores and L1-bypassing loads (sc1), 16 bytes per lane
 __device__ __forceinline__ float4 ld_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16));
@@ -149,6 +173,7 @@ struct FlowRingArgs {
     const void* w_in_lo; const void* w_out_lo;   // second terms of two-term matrices (float engine), else null
     const void* w1[kFlowRingMaxBlocks]; const void* w2[kFlowRingMaxBlocks];
     const void* w1l[kFlowRingMaxBlocks]; const void* w2l[kFlowRingMaxBlocks];
+    const float* s1[kFlowRingMaxBlocks]; const float* s2[kFlowRingMaxBlocks];   // int8 blocks: per-output-column weight scales
     const float* b1[kFlowRingMaxBlocks]; const float* b2[kFlowRingMaxBlocks];
     const float* ln_g[kFlowRingMaxBlocks]; const float* ln_b[kFlowRingMaxBlocks];
     float* ws; unsigned ws_bytes;        // hstage [blocks][B][C] then part [blocks][G][B][C], f32
@@ -161,10 +186,14 @@ struct FlowRingArgs {
 // (column slices of fc1 = K-slices of fc2): 4 keeps 256 registers of matrices per lane and halves the partial slabs a
 // visit reads and the number of consumers that read them; 8 keeps 128.  WS: every matrix comes as two bf16 terms (the float
 // engine's matrices to ~16 mantissa bits) and every tile takes a third MFMA; the register budget then allows G = 8 only.
-template <int RPG, int G, bool WS>
+// Q8: the residual blocks' matrices are int8 with per-column scales and their inputs are quantised per row and 64-wide block
+// (v_mfma_i32_16x16x64_i8, half the matrix registers); the in / out projections stay bf16.
+template <int RPG, int G, bool WS, bool Q8>
 __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
     constexpr int NT1 = NT / G, NW1 = NT1 / kWaves, KS2 = KS / G, CS = C / G, LDA2 = lda2_of(G);
+    constexpr int KS2Q = KSQ / G, LDSQ = CS + 16;
     static_assert(NW1 >= 1 && NW1 * kWaves == NT1 && KS2 * G == KS, "flow ring: slices must divide the tiles of fc1 and the k-steps of fc2");
+    static_assert(!(WS && Q8) && (!Q8 || (KS2Q * G == KSQ && (CS / 4) % 16 == 0)), "flow ring: int8 blocks need whole 64-wide blocks per slice");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* hbuf = (float*)smem;                              // [RPG][C] f32: input-projection result; K-part sums of the output projection
     __bf16* A0 = (__bf16*)(hbuf + RPG * C);                   // [2][RPG][LDA]
@@ -176,7 +205,13 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
     float* tbuf = (float*)(X1 + RPG * LDX);                   // [waves][RPG][128] f32: per-wave transpose of the fc2 tiles
     float* xkeep = tbuf + kWaves * RPG * kTw;                 // [local groups][RPG][L] f32: x of this workgroup's row groups (block 0)
     int* sflag = (int*)(xkeep + ((a.ngroups + a.replicas - 1) / a.replicas) * RPG * L);
-    uint4* win_l = (uint4*)(sflag + 4);                       // block 0: input projection [NT][64 lanes] fragments, then output projection [NTL * KS][64]
+    // int8 blocks: the quantised LayerNorm rows and their block scales, the SiLU slice in f32, quantised, and its block scales
+    signed char* Aq = (signed char*)(sflag + 4);             // [RPG][LDQ]
+    float* dA = (float*)(Aq + RPG * LDQ);                     // [KSQ][RPG]
+    float* Sf = dA + KSQ * RPG;                               // [RPG][CS]
+    signed char* Sq = (signed char*)(Sf + RPG * CS);          // [RPG][LDSQ]
+    float* dS = (float*)(Sq + RPG * LDSQ);                    // [KS2Q][RPG]
+    uint4* win_l = (uint4*)((unsigned char*)(sflag + 4) + (Q8 ? q8_lds_bytes(G) : 0));   // block 0: input projection [NT][64 lanes] fragments, then output projection [NTL * KS][64]
     uint4* wout_l = win_l + NT * 64;
     uint4* win_lo = wout_l + NTL * KS * 64;                   // WS: the second terms, same shapes
     uint4* wout_lo = win_lo + NT * 64;
@@ -194,8 +229,29 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
 
     // ---- this workgroup's matrices, once: fc1 tile `wave` of slice g over all of K; fc2 tiles 8 * wave .. 8 * wave + 7
     // (128 consecutive columns: four whole 128-byte lines of every output row) for K-slice g
-    uint4 wf1[NW1][KS], wf2[T2][KS2];
+    uint4 wf1[Q8 ? 1 : NW1][Q8 ? 1 : KS], wf2[Q8 ? 1 : T2][Q8 ? 1 : KS2];
+    uint4 wq1[Q8 ? NW1 : 1][Q8 ? KSQ : 1], wq2[Q8 ? T2 : 1][Q8 ? KS2Q : 1];
+    float sc1[Q8 ? NW1 : 1], sc2[Q8 ? T2 : 1];
     uint4 wf1l[WS ? NW1 : 1][WS ? KS : 1], wf2l[WS ? T2 : 1][WS ? KS2 : 1];
+    if constexpr (Q8) {
+        wf1[0][0] = make_uint4(0u, 0u, 0u, 0u); wf2[0][0] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int t = 0; t < NW1; ++t) {
+            const uint4* w1p = (const uint4*)a.w1[blk] + ((long long)(g * NT1 + wave * NW1 + t) * KSQ) * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < KSQ; ++ks) wq1[t][ks] = w1p[ks * 64];
+            sc1[t] = a.s1[blk][g * CS + (wave * NW1 + t) * 16 + ccol];
+        }
+        const uint4* w2p = (const uint4*)a.w2[blk] + (long long)(g * KS2Q) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < T2; ++i) {
+#pragma unroll
+            for (int ks = 0; ks < KS2Q; ++ks) wq2[i][ks] = w2p[((long long)(T2 * wave + i) * KSQ + ks) * 64];
+            sc2[i] = a.s2[blk][(T2 * wave + i) * 16 + ccol];
+        }
+    } else {
+        wq1[0][0] = make_uint4(0u, 0u, 0u, 0u); wq2[0][0] = make_uint4(0u, 0u, 0u, 0u); sc1[0] = 0.f; sc2[0] = 0.f;
+    }
     if constexpr (WS) {
 #pragma unroll
         for (int t = 0; t < NW1; ++t) {
@@ -212,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
     } else {
         wf1l[0][0] = make_uint4(0u, 0u, 0u, 0u); wf2l[0][0] = make_uint4(0u, 0u, 0u, 0u);
     }
-    {
+    if constexpr (!Q8) {
 #pragma unroll
         for (int t = 0; t < NW1; ++t) {
             const uint4* w1p = (const uint4*)a.w1[blk] + ((long long)(g * NT1 + wave * NW1 + t) * KS) * 64 + lane;
@@ -417,19 +473,59 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
                 const float mean = wsum(((h0.x + h0.y) + (h0.z + h0.w)) + ((h1.x + h1.y) + (h1.z + h1.w))) * (1.0f / (float)C);
                 const float d0 = h0.x - mean, d1 = h0.y - mean, d2 = h0.z - mean, d3 = h0.w - mean;
                 const float d4 = h1.x - mean, d5 = h1.y - mean, d6 = h1.z - mean, d7 = h1.w - mean;
-                const float rstd = __builtin_amdgcn_rsqf(wsum(((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7))) * (1.0f / (float)C) + a.eps);
+                const float var = wsum(((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7))) * (1.0f / (float)C) + a.eps;
+                const float rstd = Q8 ? 1.0f / sqrtf(var) : __builtin_amdgcn_rsqf(var);
                 float4 y0, y1;
                 y0.x = (d0 * rstd * lg0.x + lb0.x) * (1.0f + sc0.x) + sh0.x; y0.y = (d1 * rstd * lg0.y + lb0.y) * (1.0f + sc0.y) + sh0.y;
                 y0.z = (d2 * rstd * lg0.z + lb0.z) * (1.0f + sc0.z) + sh0.z; y0.w = (d3 * rstd * lg0.w + lb0.w) * (1.0f + sc0.w) + sh0.w;
                 y1.x = (d4 * rstd * lg1.x + lb1.x) * (1.0f + sc1v.x) + sh1.x; y1.y = (d5 * rstd * lg1.y + lb1.y) * (1.0f + sc1v.y) + sh1.y;
                 y1.z = (d6 * rstd * lg1.z + lb1.z) * (1.0f + sc1v.z) + sh1.z; y1.w = (d7 * rstd * lg1.w + lb1.w) * (1.0f + sc1v.w) + sh1.w;
-                put4(A0, A1, wave * LDA + c0, y0);
-                put4(A0, A1, wave * LDA + c1, y1);
+                if constexpr (Q8) {   // a 64-wide block is the float4 pieces of 16 consecutive lanes
+                    const float m0 = q8_absmax16(y0), m1 = q8_absmax16(y1);
+                    *(unsigned*)(Aq + wave * LDQ + c0) = q8_pack4(y0, m0 > 0.f ? 127.0f / m0 : 0.f);
+                    *(unsigned*)(Aq + wave * LDQ + c1) = q8_pack4(y1, m1 > 0.f ? 127.0f / m1 : 0.f);
+                    if (ccol == 0) { dA[lq * RPG + wave] = m0 / 127.0f; dA[(4 + lq) * RPG + wave] = m1 / 127.0f; }
+                } else {
+                    put4(A0, A1, wave * LDA + c0, y0);
+                    put4(A0, A1, wave * LDA + c1, y1);
+                }
             }
             __syncthreads();
             RING_STAMP(4);
             // ---- fc1: this workgroup's C / G columns, NW1 tiles per wave over all of K
-            {
+            if constexpr (Q8) {
+                float v[NW1];
+#pragma unroll
+                for (int t = 0; t < NW1; ++t) v[t] = 0.f;
+                // every fragment and block scale is requested before the first MFMA (one LDS latency, not one per k-step)
+                i32x4 a4[KSQ];
+                float d[KSQ];
+#pragma unroll
+                for (int ks = 0; ks < KSQ; ++ks) { a4[ks] = *(const i32x4*)(Aq + (lane & (RPG - 1)) * LDQ + ks * 64 + 16 * lq); d[ks] = dA[ks * RPG + lq]; }
+                __builtin_amdgcn_sched_barrier(0);
+                i32x4 ci[NW1][KSQ];
+#pragma unroll
+                for (int ks = 0; ks < KSQ; ++ks) {
+#pragma unroll
+                    for (int t = 0; t < NW1; ++t)
+                        ci[t][ks] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a4[ks], __builtin_bit_cast(i32x4, wq1[t][ks]), i32x4{0, 0, 0, 0}, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KSQ; ++ks) {   // block sums in k order, as the launch chain forms them
+#pragma unroll
+                    for (int t = 0; t < NW1; ++t) v[t] += (float)own_row_i(ci[t][ks], lq) * d[ks];
+                }
+#pragma unroll
+                for (int t = 0; t < NW1; ++t) Sf[lq * CS + (wave * NW1 + t) * 16 + ccol] = silu_exact(v[t] * sc1[t] + bias1[t]);
+                __syncthreads();
+                for (int id = tid; id < RPG * (CS / 4); id += kThreads) {   // whole waves: a block's 16 pieces sit in one DPP row
+                    const int row = id / (CS / 4), piece = id % (CS / 4);
+                    const float4 y = *(const float4*)(Sf + row * CS + 4 * piece);
+                    const float m = q8_absmax16(y);
+                    *(unsigned*)(Sq + row * LDSQ + 4 * piece) = q8_pack4(y, m > 0.f ? 127.0f / m : 0.f);
+                    if ((piece & 15) == 0) dS[(piece >> 4) * RPG + row] = m / 127.0f;
+                }
+            } else {
                 // groups of 4 k-steps: the fragment reads of group n + 1 are issued before the MFMAs of group n (the pins keep
                 // the compiler from sinking each read to its use, which exposes one LDS latency per MFMA pair)
                 constexpr int GK = 4, NG = KS / GK;
@@ -468,6 +564,26 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
             // ---- fc2: every output column, this workgroup's K-slice -> partial slab, stored as whole lines
             {
                 float* tw = tbuf + wave * RPG * kTw;
+                if constexpr (Q8) {
+                    i32x4 sq[KS2Q];
+                    float ds[KS2Q];
+#pragma unroll
+                    for (int ks = 0; ks < KS2Q; ++ks) { sq[ks] = *(const i32x4*)(Sq + (lane & (RPG - 1)) * LDSQ + ks * 64 + 16 * lq); ds[ks] = dS[ks * RPG + lq]; }
+                    i32x4 ci[T2][KS2Q];
+#pragma unroll
+                    for (int i = 0; i < T2; ++i) {
+#pragma unroll
+                        for (int ks = 0; ks < KS2Q; ++ks)
+                            ci[i][ks] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sq[ks], __builtin_bit_cast(i32x4, wq2[i][ks]), i32x4{0, 0, 0, 0}, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < T2; ++i) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int ks = 0; ks < KS2Q; ++ks) v += (float)own_row_i(ci[i][ks], lq) * ds[ks];
+                        tw[lq * kTw + i * 16 + ccol] = v * sc2[i];
+                    }
+                } else {
                 bf16x8 sh_[KS2], sl_[KS2];
 #pragma unroll
                 for (int ks = 0; ks < KS2; ++ks) { sh_[ks] = afrag<RPG>(S0, LDA2, ks * KSTEP, lane); sl_[ks] = afrag<RPG>(S1, LDA2, ks * KSTEP, lane); }
@@ -481,6 +597,7 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < T2; ++i) tw[lq * kTw + i * 16 + ccol] = own_row(acc2[i], lq);
+                }
                 __builtin_amdgcn_wave_barrier();
                 // lane -> (row u, 16-byte chunk c of the wave's 512-byte run): 8 consecutive lanes write one whole 128-byte line
 #pragma unroll
@@ -530,7 +647,7 @@ bool flow_ring_supported(const FlowHeadArgs& a) {
     if (std::getenv("FLOW_HEAD_NO_RING")) return false;
     const int bw = a.block_wtype < 0 ? a.wtype : a.block_wtype;
     const bool split = a.wtype == W_F32 && bw == W_F32 && a.ring_split;
-    if (!split && !(a.wtype == W_BF16 && bw == W_BF16)) return false;
+    if (!split && !(a.wtype == W_BF16 && (bw == W_BF16 || bw == W_I8))) return false;
     const int G = ring_slices(split);
     return a.C == C && a.L == L && a.blocks >= 2 && a.blocks <= kFlowRingMaxBlocks && a.steps >= 1 &&
            a.ring_ctl != nullptr && a.B >= 1 && a.ring_wg_budget >= a.blocks * G;
@@ -567,11 +684,11 @@ size_t flow_ring_ctl_bytes(int B, int blocks) {
 size_t flow_ring_err_word(int, int) { return 0; }
 size_t flow_ring_counter_word() { return kCtlStride; }
 
-static size_t ring_smem(int rpg, int ngroups, int replicas, bool split) {
+static size_t ring_smem(int rpg, int ngroups, int replicas, bool split, bool q8) {
     const int local = (ngroups + replicas - 1) / replicas;
     const int LDA2 = lda2_of(ring_slices(split));
     return (size_t)rpg * C * 4 + (size_t)2 * rpg * (LDA + LDA2 + LDX) * 2 + (size_t)kWaves * rpg * kTw * 4 + (size_t)local * rpg * L * 4 + 16 +
-           (size_t)(NT + NTL * KS) * 64 * 16 * (split ? 2 : 1);
+           (q8 ? q8_lds_bytes(ring_slices(split)) : 0) + (size_t)(NT + NTL * KS) * 64 * 16 * (split ? 2 : 1);
 }
 
 static void ring_lds_limit(const void* kernel) {
@@ -584,9 +701,11 @@ static void ring_lds_limit(const void* kernel) {
 }
 
 void flow_ring_prepare() {
-    ring_lds_limit((const void*)flow_ring_kernel<4, 8, false>);
-    ring_lds_limit((const void*)flow_ring_kernel<4, 4, false>);
-    ring_lds_limit((const void*)flow_ring_kernel<4, 8, true>);
+    ring_lds_limit((const void*)flow_ring_kernel<4, 8, false, false>);
+    ring_lds_limit((const void*)flow_ring_kernel<4, 4, false, false>);
+    ring_lds_limit((const void*)flow_ring_kernel<4, 8, true, false>);
+    ring_lds_limit((const void*)flow_ring_kernel<4, 8, false, true>);
+    ring_lds_limit((const void*)flow_ring_kernel<4, 4, false, true>);
 }
 
 // The caller has zeroed a.ring_ctl (flow_ring_ctl_bytes) earlier on the same stream.
@@ -595,6 +714,7 @@ void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s) {
     if (a.x_out == a.x0) throw std::runtime_error("flow ring: x_out must not alias x0");
     int rpg = 4, replicas = 1;
     const bool split = a.wtype == W_F32;
+    const bool q8 = (a.block_wtype < 0 ? a.wtype : a.block_wtype) == W_I8;
     flow_ring_shape(a.B, a.blocks, a.ring_wg_budget, split, rpg, replicas);
     FlowRingArgs r{};
     r.x0 = a.x0; r.x0_stride = a.x0_stride; r.x0_step = a.x0_step; r.x0_step_stride = a.x0_step_stride; r.x0_step_bias = a.x0_step_bias; r.step_ring = a.step_ring;
@@ -610,6 +730,8 @@ void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s) {
     for (int i = 0; i < a.blocks; ++i) {
         r.w1[i] = t.r_fc1[i]; r.w2[i] = t.r_fc2[i]; r.b1[i] = t.b_fc1[i]; r.b2[i] = t.b_fc2[i]; r.ln_g[i] = t.ln_g[i]; r.ln_b[i] = t.ln_b[i];
         r.w1l[i] = split ? t.r_fc1_lo[i] : nullptr; r.w2l[i] = split ? t.r_fc2_lo[i] : nullptr;
+        r.s1[i] = q8 ? t.s_fc1[i] : nullptr; r.s2[i] = q8 ? t.s_fc2[i] : nullptr;
+        if (q8 && (!r.s1[i] || !r.s2[i])) throw std::runtime_error("flow ring: int8 blocks without weight scales");
     }
     r.ws = a.workspace;
     const size_t wsb = flow_ring_workspace_bytes(a.B, a.blocks);
@@ -618,14 +740,16 @@ void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s) {
     r.ctl = a.ring_ctl;
     r.eps = a.eps; r.dt = 1.0f / (float)a.steps;
     r.stamps = a.cycle_probe;
-    const size_t smem = ring_smem(rpg, r.ngroups, replicas, split);
+    const size_t smem = ring_smem(rpg, r.ngroups, replicas, split, q8);
     if (smem > 160 * 1024) throw std::runtime_error("flow ring: LDS request too large");
     const int G = ring_slices(split);
     const int grid = replicas * a.blocks * G;
     if (a.probe_a) (void)hipEventRecord(a.probe_a, s);
-    if (split) hipLaunchKernelGGL((flow_ring_kernel<4, 8, true>), dim3(grid), dim3(kThreads), smem, s, r);
-    else if (G == 8) hipLaunchKernelGGL((flow_ring_kernel<4, 8, false>), dim3(grid), dim3(kThreads), smem, s, r);
-    else hipLaunchKernelGGL((flow_ring_kernel<4, 4, false>), dim3(grid), dim3(kThreads), smem, s, r);
+    if (split) hipLaunchKernelGGL((flow_ring_kernel<4, 8, true, false>), dim3(grid), dim3(kThreads), smem, s, r);
+    else if (q8 && G == 8) hipLaunchKernelGGL((flow_ring_kernel<4, 8, false, true>), dim3(grid), dim3(kThreads), smem, s, r);
+    else if (q8) hipLaunchKernelGGL((flow_ring_kernel<4, 4, false, true>), dim3(grid), dim3(kThreads), smem, s, r);
+    else if (G == 8) hipLaunchKernelGGL((flow_ring_kernel<4, 8, false, false>), dim3(grid), dim3(kThreads), smem, s, r);
+    else hipLaunchKernelGGL((flow_ring_kernel<4, 4, false, false>), dim3(grid), dim3(kThreads), smem, s, r);
     if (a.probe_b) (void)hipEventRecord(a.probe_b, s);
 }
 
