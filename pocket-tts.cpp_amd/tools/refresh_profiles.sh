@@ -37,6 +37,8 @@ timeout -k 10 600 python3 bench.py > "$OUT/${R}_bench.json"
 timeout -k 10 600 python3 bench.py --workload c4 --no-cpu-baseline > "$OUT/${R}_bench_c4.json"
 timeout -k 10 600 python3 bench.py --workload c4 --no-cpu-baseline --no-extras --engines-per-gpu 1 > "$OUT/${R}_bench_c4_one_engine.json"
 timeout -k 10 600 python3 bench.py --workload c4 --no-cpu-baseline --no-extras --precision bf16 > "$OUT/${R}_bench_c4_bf16.json"
+timeout -k 10 600 python3 bench.py --no-cpu-baseline --no-extras --precision fp32 > "$OUT/${R}_bench_fp32.json"
+timeout -k 10 600 python3 bench.py --no-cpu-baseline --no-extras --frames 500 > "$OUT/${R}_bench_500_frames.json"
 if [ -x pocket-tts.cpp_amd/xcd_probe ]; then timeout -k 5 60 pocket-tts.cpp_amd/xcd_probe > "$OUT/${R}_xcd_probe.txt"; fi
 timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/latency_probe.py --runs 20 > "$OUT/${R}_latency_fp32.json"
 timeout -k 10 300 python3 pocket-tts.cpp_amd/tools/latency_probe.py --runs 20 --precision bf16 > "$OUT/${R}_latency_bf16.json"
