@@ -139,11 +139,29 @@ static void bench_gemm(const char* name, int M, int N, int K, int split_a, int l
 static void bench_flow(int B) {
     const char* wenv = std::getenv("KB_FLOW_WTYPE");
     const int W_T = wenv && !std::strcmp(wenv, "f32") ? W_F32 : W_BF16;
+    const bool q8 = wenv && !std::strcmp(wenv, "i8");   // int8 residual blocks, bf16 in / out projections
     const int C = 512, L = 32, nb = std::getenv("KB_FLOW_BLOCKS") ? std::atoi(std::getenv("KB_FLOW_BLOCKS")) : 6, steps = 10, mw = nb * 3 * C + 2 * C;
     FlowHostTabs tabs;
     for (int i = 0; i < nb; ++i) {
-        tabs.w_fc1.push_back(packed_weight(C, C, W_T));
-        tabs.w_fc2.push_back(packed_weight(C, C, W_T));
+        if (q8) {
+            for (int k = 0; k < 2; ++k) {
+                auto w = rnd((size_t)C * C);
+                std::vector<float> sc;
+                auto bytes = pack_q8_weight(w.data(), C, C, sc);
+                void* wp = nullptr;
+                CK(hipMalloc(&wp, bytes.size()));
+                CK(hipMemcpy(wp, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+                float* sp = nullptr;
+                CK(hipMalloc(&sp, sc.size() * 4));
+                CK(hipMemcpy(sp, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+                (k ? tabs.w_fc2 : tabs.w_fc1).push_back(wp);
+                (k ? tabs.s_fc2 : tabs.s_fc1).push_back(sp);
+            }
+        } else {
+            tabs.w_fc1.push_back(packed_weight(C, C, W_T));
+            tabs.w_fc2.push_back(packed_weight(C, C, W_T));
+            tabs.s_fc1.push_back(nullptr); tabs.s_fc2.push_back(nullptr);
+        }
         tabs.b_fc1.push_back((const float*)dalloc(C * 4)); tabs.b_fc2.push_back((const float*)dalloc(C * 4));
         tabs.ln_g.push_back((const float*)dalloc(C * 4)); tabs.ln_b.push_back((const float*)dalloc(C * 4));
     }
@@ -156,6 +174,7 @@ static void bench_flow(int B) {
     a.w_out = packed_weight(L, C, W_T); a.b_out = (const float*)dalloc(L * 4);
     if (W_T == W_BF16) { tabs.r_fc1 = tabs.w_fc1; tabs.r_fc2 = tabs.w_fc2; tabs.r_in = a.w_in; tabs.r_out = a.w_out; }   // the persistent form's planes
     a.host_tabs = &tabs; a.workspace = (float*)dalloc(flow_head_workspace_bytes(B, C, W_T, nb), 0); a.wtype = W_T;
+    if (q8) a.block_wtype = W_I8;
     flow_head_prepare(C, W_T);
     if (std::getenv("KB_FLOW_RING")) {
         // persistent form against the launch chain: same inputs, outputs compared, then timed (its control words are cleared
@@ -163,7 +182,7 @@ static void bench_flow(int B) {
         const size_t ctl_bytes = flow_ring_ctl_bytes(B, nb);
         unsigned* ctl = (unsigned*)dalloc(ctl_bytes, 0);
         std::vector<float> ref((size_t)B * L), got((size_t)B * L);
-        setenv("FLOW_HEAD_SPLIT", "8", 1);   // the chain variant whose sums are formed in the same order
+        if (!q8) setenv("FLOW_HEAD_SPLIT", "8", 1);   // the chain variant whose sums are formed in the same order
         launch_flow_head(a, 0);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(ref.data(), a.x_out, ref.size() * 4, hipMemcpyDeviceToHost));
