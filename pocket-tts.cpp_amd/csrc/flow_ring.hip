@@ -643,14 +643,22 @@ static int ring_slices(bool split) {
     return split ? 8 : g;
 }
 
+static void flow_ring_shape(int B, int blocks, int budget, bool split, int& rpg, int& replicas);
+static size_t ring_smem(int rpg, int ngroups, int replicas, bool split, bool q8);
+
 bool flow_ring_supported(const FlowHeadArgs& a) {
     if (std::getenv("FLOW_HEAD_NO_RING")) return false;
     const int bw = a.block_wtype < 0 ? a.wtype : a.block_wtype;
     const bool split = a.wtype == W_F32 && bw == W_F32 && a.ring_split;
     if (!split && !(a.wtype == W_BF16 && (bw == W_BF16 || bw == W_I8))) return false;
     const int G = ring_slices(split);
-    return a.C == C && a.L == L && a.blocks >= 2 && a.blocks <= kFlowRingMaxBlocks && a.steps >= 1 &&
-           a.ring_ctl != nullptr && a.B >= 1 && a.ring_wg_budget >= a.blocks * G;
+    if (!(a.C == C && a.L == L && a.blocks >= 2 && a.blocks <= kFlowRingMaxBlocks && a.steps >= 1 &&
+          a.ring_ctl != nullptr && a.B >= 1 && a.ring_wg_budget >= a.blocks * G))
+        return false;
+    // the row groups a workgroup serves keep their x rows in LDS: many rows on few replicas may not fit (the launch chain runs then)
+    int rpg = 4, replicas = 1;
+    flow_ring_shape(a.B, a.blocks, a.ring_wg_budget, split, rpg, replicas);
+    return ring_smem(rpg, (a.B + rpg - 1) / rpg, replicas, split, bw == W_I8) <= 160 * 1024;
 }
 
 // Row-group height and replica count for B rows.  More replicas shorten each workgroup's queue of row groups; the
