@@ -262,6 +262,8 @@ int main(int argc, char** argv) {
     if (want("skinny_q8_qkv")) bench_skinny_q8("skinny_q8_qkv", 64, 3072, 1024, 1);
     if (want("skinny_q8_ff2")) bench_skinny_q8("skinny_q8_ff2", 64, 1024, 4096, 16);
     if (want("gemm_ada")) bench_gemm("gemm_ada", 640, 10240, 512, 1);
+    if (want("gemm_pre_qkv")) bench_gemm("gemm_pre_qkv", 6016, 3072, 1024, 1);
+    if (want("gemm_pre_ff2")) bench_gemm("gemm_pre_ff2", 6016, 1024, 4096, 1);
     if (want("gemm_dec_qkv")) bench_gemm("gemm_dec_qkv", 15360, 1536, 512, 0);
     if (want("gemm_dec_ff2")) bench_gemm("gemm_dec_ff2", 15360, 512, 2048, 0);
     if (want("gemm_conv0")) bench_gemm("gemm_conv0", 15360, 512, 3584, 0, 512);
