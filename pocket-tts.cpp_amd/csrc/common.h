@@ -110,6 +110,9 @@ struct DevBuf {
 // legacy stream depend on a capturing blocking stream"): engines on several GPUs, or several on one, capture their frame
 // graphs while others are being created or are growing their buffers.
 void sync_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+// The stream those run on (one per device for the whole process), for asynchronous side work that must not sit in front of
+// an engine's frame loop: the slot table's prefill passes.  Never destroyed.
+hipStream_t shared_side_stream();
 void sync_fill(void* dst, int value, size_t bytes);
 
 }  // namespace ptts

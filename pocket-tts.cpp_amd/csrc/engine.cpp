@@ -521,14 +521,20 @@ Batch::Batch(Engine& e, int B_, bool lm_only_) : B(B_), Bw(B_), lm_only(lm_only_
 // reallocation drops the graphs; the next run captures them again on the new buffers.
 void Batch::ensure_rows(size_t rows, int d, int ffn) {
     const size_t need_d = rows * d, need_f = rows * ffn;
+    // (the batch's own streams are drained, not the device: a device-wide wait is refused while another engine's thread
+    // is capturing its frame graphs)
+    auto drain = [&] {
+        if (st) PTTS_HIP(hipStreamSynchronize(st));
+        if (dec_st && dec_st != st) PTTS_HIP(hipStreamSynchronize(dec_st));
+    };
     if (need_d > scratch_rows_d) {
-        PTTS_HIP(hipDeviceSynchronize());
+        drain();
         drop_graphs();
         x.alloc(need_d * 4); h.alloc(need_d * 4); q.alloc(need_d * 4); att.alloc(need_d * 4); qkv.alloc(need_d * 3 * 4);
         scratch_rows_d = need_d;
     }
     if (need_f > scratch_rows_f) {
-        PTTS_HIP(hipDeviceSynchronize());
+        drain();
         drop_graphs();
         ff.alloc(need_f * 4);
         scratch_rows_f = need_f;
@@ -619,6 +625,7 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
         PTTS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         PTTS_HIP(hipStreamCreateWithPriority(&dec_stream_, hipStreamNonBlocking, lo));
     }
+    prefill_stream_ = shared_side_stream();   // one per device for the whole process: see pack.cpp
     PTTS_HIP(hipEventCreateWithFlags(&latents_ready_, hipEventDisableTiming));
     PTTS_HIP(hipEventCreateWithFlags(&dec_done_, hipEventDisableTiming));
     lanes_ = opt_.lanes;
@@ -750,6 +757,7 @@ Engine::~Engine() {
     if (latents_ready_) (void)hipEventDestroy(latents_ready_);
     if (dec_done_) (void)hipEventDestroy(dec_done_);
     if (dec_stream_) { (void)hipStreamSynchronize(dec_stream_); (void)hipStreamDestroy(dec_stream_); }
+    if (prefill_stream_) (void)hipStreamSynchronize(prefill_stream_);   // shared, not this engine's to destroy
     if (stream_) (void)hipStreamDestroy(stream_);
     PTTS_TRACE("dtor: streams destroyed");
 }
@@ -951,7 +959,7 @@ void Engine::lm_rows_skinny(Batch& b, int slot0, int nb, int rpb, float* X) {
     hipStream_t st = b.st;
     const size_t need = static_cast<size_t>(std::max(s_out, s_ff2)) * M * D * 4;
     if (b.pre_partial.bytes < need) {
-        PTTS_HIP(hipDeviceSynchronize());
+        PTTS_HIP(hipStreamSynchronize(st));
         b.pre_partial.alloc(need);
     }
     const long long layer_stride = static_cast<long long>(b.B) * b.lm_cap * D;

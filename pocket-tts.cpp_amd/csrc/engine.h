@@ -278,6 +278,7 @@ private:
     EngineOptions opt_;
     std::unique_ptr<Model> model_;
     hipStream_t stream_ = nullptr;
+    hipStream_t prefill_stream_ = nullptr;      // prefill passes of the slot table while other slots keep stepping (the process-wide side stream of the device)
     hipStream_t dec_stream_ = nullptr;          // the Mimi decoder runs here, beside the frame loop
     hipEvent_t latents_ready_ = nullptr, dec_done_ = nullptr;
     std::mutex mu_;

@@ -114,7 +114,7 @@ struct AdmitArgs {
     int L = 0, ring = 0, frames = 0, g0 = 0;
     float* noise_ring = nullptr;
     const float* noise_stage = nullptr;
-    unsigned char slot[64] = {}, has_noise[64] = {};
+    unsigned char slot[64] = {}, src[64] = {}, has_noise[64] = {};   // destination slot, row of the staging batch, start points given
     int len[64] = {};
 };
 void launch_admit(const AdmitArgs& a, hipStream_t s);

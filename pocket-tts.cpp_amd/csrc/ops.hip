@@ -233,16 +233,16 @@ void launch_reset_pos_mask(int* pos, unsigned long long mask, hipStream_t s) {
 // the blocks with y == 0 also fill the newcomer's start-point ring rows, block (0, 0, i) its position and BOS row.
 __global__ __launch_bounds__(256) void admit_kernel(AdmitArgs a) {
     const int i = blockIdx.z, layer = blockIdx.y >> 1, tid = threadIdx.x;
-    const int slot = a.slot[i];
+    const int slot = a.slot[i], si = a.src[i];
     const size_t slot_bytes = static_cast<size_t>(a.cap) * a.row_bytes;
     const size_t n16 = static_cast<size_t>(a.len[i]) * a.row_bytes / 16;
-    const char* src = ((blockIdx.y & 1) ? a.v_src : a.k_src) + (static_cast<size_t>(layer) * a.src_slots + i) * slot_bytes;
+    const char* src = ((blockIdx.y & 1) ? a.v_src : a.k_src) + (static_cast<size_t>(layer) * a.src_slots + si) * slot_bytes;
     char* dst = ((blockIdx.y & 1) ? a.v_dst : a.k_dst) + (static_cast<size_t>(layer) * a.dst_slots + slot) * slot_bytes;
     for (size_t j = blockIdx.x * 256 + tid; j < n16; j += gridDim.x * 256)
         reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(src)[j];
     if (blockIdx.y == 0) {
         float* ring = a.noise_ring + static_cast<size_t>(slot) * a.ring * a.L;
-        const float* nz = a.noise_stage + static_cast<size_t>(i) * a.frames * a.L;
+        const float* nz = a.noise_stage + static_cast<size_t>(si) * a.frames * a.L;
         const bool has = a.has_noise[i] != 0;
         for (int j = blockIdx.x * 256 + tid; j < a.frames * a.L; j += gridDim.x * 256) {
             const int f = j / a.L, c = j - f * a.L;

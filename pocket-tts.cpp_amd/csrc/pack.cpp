@@ -41,7 +41,10 @@ void trace_fmt(const char* fmt, ...) {
 }
 
 namespace {
-// one stream per device, made on first use and kept for the life of the process; the mutex also orders the callers
+// One stream per device, made on first use and kept for the life of the process; the mutex also orders the callers.  One
+// for the whole process on purpose: a process gets few hardware queues per GPU (GPU_MAX_HW_QUEUES, 4 by default), streams
+// beyond that share queues, and two streams on one queue run one after the other (measured: two engines with a side stream
+// each fell from 7550 to 4180 RTFx).  The engines' frame-loop streams should have queues to themselves.
 std::mutex g_util_mu;
 hipStream_t g_util_stream[64];
 
@@ -53,6 +56,11 @@ hipStream_t util_stream_locked() {
     return s;
 }
 }  // namespace
+
+hipStream_t shared_side_stream() {
+    std::lock_guard<std::mutex> g(g_util_mu);
+    return util_stream_locked();
+}
 
 void sync_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
     if (bytes == 0) return;

@@ -71,6 +71,14 @@ struct Engine::Table {
     struct Delivery { hipEvent_t ev = nullptr; int slab = -1; int slot0 = 0, n = 0; std::vector<Item> items; };
 
     std::unique_ptr<Batch> b, pb;        // the table's state, and the staging batch prefill passes run in
+    // Utterances whose prefill is in the staging batch (row i of it) and that wait for a slot or for their step of the clock.
+    // While other slots are stepping, the pass runs on the prefill stream beside the frame loop instead of in front of it.
+    std::vector<Request*> staged;
+    std::vector<char> staged_in;         // row already moved into a slot
+    std::vector<int> staged_len;
+    std::vector<unsigned char> staged_noise;
+    bool staged_side = false, admit_pending = false;
+    hipEvent_t staged_done = nullptr, admit_done = nullptr;   // end of the pass on the prefill stream; last move out of the staging batch
     std::array<Slot, kSlots> slots;
     int occupied = 0;
     bool graphs_ready = false;
@@ -117,6 +125,8 @@ struct Engine::Table {
         if (h_voice) (void)hipHostFree(h_voice);
         if (h_ids) (void)hipHostFree(h_ids);
         if (h_noise) (void)hipHostFree(h_noise);
+        if (staged_done) (void)hipEventDestroy(staged_done);
+        if (admit_done) (void)hipEventDestroy(admit_done);
         for (auto& d : deliveries) if (d.ev) (void)hipEventDestroy(d.ev);
         for (auto& e : free_events) (void)hipEventDestroy(e);
     }
@@ -389,12 +399,19 @@ void Engine::worker_main() {
                 // have been finished by the delivery thread
                 for (size_t j = T.due_pushed; j < T.due_reqs.size(); ++j)
                     if (std::find(victims.begin(), victims.end(), T.due_reqs[j]) == victims.end()) victims.push_back(T.due_reqs[j]);
+                for (size_t j = 0; j < T.staged.size(); ++j)
+                    if (!T.staged_in[j] && std::find(victims.begin(), victims.end(), T.staged[j]) == victims.end()) victims.push_back(T.staged[j]);
+                T.staged.clear(); T.staged_in.clear();
                 for (auto& sl : T.slots)
                     if (sl.req) {
                         if (std::find(victims.begin(), victims.end(), sl.req) == victims.end()) victims.push_back(sl.req);
                         sl.req = nullptr;
                     }
-                (void)hipDeviceSynchronize();
+                // this engine's streams only: a device-wide wait is refused while another engine's thread captures a graph
+                (void)hipStreamSynchronize(stream_);
+                (void)hipStreamSynchronize(dec_stream_);
+                (void)hipStreamSynchronize(prefill_stream_);
+                (void)hipGetLastError();
                 drop_table();
             }
             for (Request* r : victims) Table::finish(r, err);
@@ -422,6 +439,8 @@ void Engine::run_table() {
         PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&N.h_ids), static_cast<size_t>(kSlots) * opt_.max_text_tokens * 8));
         PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&N.h_noise), static_cast<size_t>(kSlots) * F * L * 4));
         N.pb->ids_stage.alloc(static_cast<size_t>(kSlots) * opt_.max_text_tokens * 8);
+        PTTS_HIP(hipEventCreateWithFlags(&N.staged_done, hipEventDisableTiming));
+        PTTS_HIP(hipEventCreateWithFlags(&N.admit_done, hipEventDisableTiming));
         N.d_thread = std::thread([&N] { N.deliver_main(); });
     }
     Table& T = *table_;
@@ -445,6 +464,7 @@ void Engine::run_table() {
     for (auto& sl : T.slots) { sl.req = nullptr; }
     T.occupied = 0;
     T.due_reqs.clear(); T.due_pushed = 0;
+    T.staged.clear(); T.staged_in.clear(); T.staged_len.clear(); T.staged_noise.clear(); T.staged_side = false; T.admit_pending = false;
     if (!bos_row_.p) {
         bos_row_.alloc(static_cast<size_t>(L) * 4);
         std::vector<float> nanrow(L, std::numeric_limits<float>::quiet_NaN());
@@ -506,112 +526,159 @@ void Engine::run_table() {
 
     int gather_us = 100;
     if (const char* e = std::getenv("POCKET_TTS_GATHER_US")) gather_us = std::max(0, std::atoi(e));
+    const bool sync_prefill = std::getenv("POCKET_TTS_SYNC_PREFILL") != nullptr;   // every prefill pass in line, in front of the next frame
     FlagWait flag_wait;
     int gs = 0;   // the table's clock: frame steps launched so far
     for (;;) {
-        // ---- admission
-        std::vector<Request*> incoming;
-        {
-            std::unique_lock<std::mutex> lk(q_mu_);
-            if (T.occupied == 0 && gather_us > 0) {
-                // an idle table waits a moment for the rest of a burst: callers that arrive together then share one prefill
-                // pass and one chunk phase instead of trailing each other by a step (POCKET_TTS_GATHER_US, default 100)
-                const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(4 * gather_us);
-                for (size_t seen = queue_.size(); seen < static_cast<size_t>(kSlots) && std::chrono::steady_clock::now() < t_end;) {
-                    q_cv_.wait_for(lk, std::chrono::microseconds(gather_us));
-                    if (queue_.size() == seen) break;
-                    seen = queue_.size();
+        // ---- admission, in two parts: a prefill pass over queued utterances in the staging batch, then the move of finished
+        // rows into free slots.  With an empty table both happen here, in line.  While slots are stepping, the pass runs on
+        // the prefill stream beside the frame loop (for up to a table's worth of queued utterances, whether or not a slot is
+        // free yet) and its rows move in at the first step of the clock that suits them after it has ended, so nobody's frame
+        // waits for somebody else's prompt.
+        auto staged_left = [&]() { size_t n = 0; for (char c : T.staged_in) n += c ? 0 : 1; return n; };
+        if (!T.staged.empty() && staged_left() == 0) { T.staged.clear(); T.staged_in.clear(); T.staged_len.clear(); T.staged_noise.clear(); T.staged_side = false; }
+        if (T.staged.empty()) {
+            std::vector<Request*> incoming;
+            const bool side = T.occupied > 0 && !sync_prefill;
+            {
+                std::unique_lock<std::mutex> lk(q_mu_);
+                if (T.occupied == 0 && gather_us > 0) {
+                    // an idle table waits a moment for the rest of a burst: callers that arrive together then share one prefill
+                    // pass and one chunk phase instead of trailing each other by a step (POCKET_TTS_GATHER_US, default 100)
+                    const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(4 * gather_us);
+                    for (size_t seen = queue_.size(); seen < static_cast<size_t>(kSlots) && std::chrono::steady_clock::now() < t_end;) {
+                        q_cv_.wait_for(lk, std::chrono::microseconds(gather_us));
+                        if (queue_.size() == seen) break;
+                        seen = queue_.size();
+                    }
+                }
+                int room = side ? kSlots : kSlots - T.occupied;
+                for (auto it = queue_.begin(); it != queue_.end() && room > 0;) {
+                    Request* r = *it;
+                    // in line, only what can take a slot at this step is prefilled (see the rule at the move below)
+                    const int period = r->streaming ? (T.occupied < kSlots / 4 ? 1 : std::min(r->chunk_frames, kDecChunk)) : kDecChunk;
+                    if (side || T.occupied == 0 || gs % period == 0) {
+                        incoming.push_back(r);
+                        it = queue_.erase(it);
+                        --room;
+                    } else {
+                        ++it;
+                    }
                 }
             }
-            int free_slots = kSlots - T.occupied;
-            for (auto it = queue_.begin(); it != queue_.end() && free_slots > 0;) {
-                Request* r = *it;
-                // a stream joins at once while the table is lightly loaded (first-chunk latency; its chunks then fall on steps
-                // of their own and cost decoder calls of their own), on a chunk boundary of the clock once it is not
-                const int period = r->streaming ? (T.occupied < kSlots / 4 ? 1 : std::min(r->chunk_frames, kDecChunk)) : kDecChunk;
-                if (T.occupied == 0 || gs % period == 0) {
-                    incoming.push_back(r);
-                    it = queue_.erase(it);
-                    --free_slots;
-                } else {
-                    ++it;
+            if (!incoming.empty()) {
+                const int k = static_cast<int>(incoming.size());
+                hipStream_t ps = side ? prefill_stream_ : st;
+                PTTS_TRACEF("step %d: prefill of %d %s (%d in the table)", gs, k, side ? "beside the frame loop" : "in line", T.occupied);
+                // the staging batch and the pinned arrays are free again once the last move out of them has run
+                if (side && T.admit_pending) PTTS_HIP(hipStreamWaitEvent(ps, T.admit_done, 0));
+                T.admit_pending = false;
+                pb.st = ps; pb.dec_st = ps;
+                // Prefill of all newcomers in one causal pass over [voice; text] each (the reference's two passes, :572 and :575,
+                // write the same cache), padded to the longest, in the staging batch.  Inputs are gathered in pinned memory and
+                // uploaded once.
+                int vmax = 1, rpb = 1;
+                int *nv = T.h_small, *nt = T.h_small + kSlots, *len = T.h_small + 2 * kSlots;
+                for (int i = 0; i < k; ++i) {
+                    nv[i] = incoming[i]->utt.voice_frames; nt[i] = static_cast<int>(incoming[i]->utt.token_ids.size());
+                    len[i] = nv[i] + nt[i];
+                    vmax = std::max(vmax, nv[i]); rpb = std::max(rpb, len[i]);
                 }
+                if (T.h_voice_rows < static_cast<size_t>(vmax)) {
+                    if (T.h_voice) { PTTS_HIP(hipStreamSynchronize(st)); PTTS_HIP(hipStreamSynchronize(prefill_stream_)); PTTS_HIP(hipHostFree(T.h_voice)); T.h_voice = nullptr; }
+                    PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&T.h_voice), static_cast<size_t>(kSlots) * vmax * D * 4));
+                    T.h_voice_rows = static_cast<size_t>(vmax);
+                    pb.voice_stage.alloc(static_cast<size_t>(kSlots) * vmax * D * 4);
+                }
+                T.staged = incoming;
+                T.staged_in.assign(static_cast<size_t>(k), 0);
+                T.staged_len.assign(len, len + k);
+                T.staged_noise.assign(static_cast<size_t>(k), 0);
+                T.staged_side = side;
+                bool any_noise = false;
+                for (int i = 0; i < k; ++i) {
+                    const Request* r = incoming[i];
+                    const Utterance& u = r->utt;
+                    if (nv[i]) std::memcpy(T.h_voice + static_cast<size_t>(i) * vmax * D, u.voice, static_cast<size_t>(nv[i]) * D * 4);
+                    std::memcpy(T.h_ids + static_cast<size_t>(i) * opt_.max_text_tokens, u.token_ids.data(), static_cast<size_t>(nt[i]) * 8);
+                    // start points of frames 0..: explicit ones, drawn ones, or zeros (temperature 0, :606-613)
+                    const float* nz = u.noise ? u.noise : (r->noise.empty() ? nullptr : r->noise.data());
+                    T.staged_noise[static_cast<size_t>(i)] = nz ? 1 : 0;
+                    if (nz) { std::memcpy(T.h_noise + static_cast<size_t>(i) * F * L, nz, static_cast<size_t>(F) * L * 4); any_noise = true; }
+                }
+                PTTS_HIP(hipMemcpyAsync(pb.voice_stage.p, T.h_voice, static_cast<size_t>(k) * vmax * D * 4, hipMemcpyHostToDevice, ps));
+                PTTS_HIP(hipMemcpyAsync(pb.ids_stage.p, T.h_ids, static_cast<size_t>(k) * opt_.max_text_tokens * 8, hipMemcpyHostToDevice, ps));
+                if (any_noise) PTTS_HIP(hipMemcpyAsync(T.noise_stage.p, T.h_noise, static_cast<size_t>(k) * F * L * 4, hipMemcpyHostToDevice, ps));
+                PTTS_HIP(hipMemcpyAsync(pb.st_nv.p, nv, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, ps));
+                PTTS_HIP(hipMemcpyAsync(pb.st_nt.p, nt, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, ps));
+                PTTS_HIP(hipMemcpyAsync(pb.st_len.p, len, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, ps));
+                PTTS_HIP(hipMemsetAsync(pb.lm_pos.p, 0, pb.lm_pos.bytes, ps));
+                std::fill(pb.lm_pos_host.begin(), pb.lm_pos_host.end(), 0);
+                pb.ensure_rows(static_cast<size_t>(k) * rpb, D, s.lm_ffn);
+                launch_assemble_prefill(pb.voice_stage.f(), static_cast<long long>(vmax) * D, pb.ids_stage.as<long long>(), opt_.max_text_tokens,
+                                        pb.st_nv.as<int>(), pb.st_nt.as<int>(), hd_.text_embed, s.vocab + 1, D, rpb, k, pb.x.f(), ps);
+                lm_rows(pb, 0, k, rpb, pb.x.f(), pb.st_len.as<int>(), len);
+                if (side) PTTS_HIP(hipEventRecord(T.staged_done, ps));
+                check_launches("the prefill pass");
             }
         }
-        if (!incoming.empty()) {
-            const int k = static_cast<int>(incoming.size());
-            PTTS_TRACEF("step %d: %d admitted (%d in the table)", gs, k, T.occupied);
-            // Prefill of all newcomers in one causal pass over [voice; text] each (the reference's two passes, :572 and :575,
-            // write the same cache), padded to the longest, in the staging batch.  Inputs are gathered in pinned memory and
-            // uploaded once; the previous admission's uploads out of these pinned arrays ran before the step whose EOS row
-            // has since arrived.
-            int vmax = 1, rpb = 1;
-            int *nv = T.h_small, *nt = T.h_small + kSlots, *len = T.h_small + 2 * kSlots;
-            for (int i = 0; i < k; ++i) {
-                nv[i] = incoming[i]->utt.voice_frames; nt[i] = static_cast<int>(incoming[i]->utt.token_ids.size());
-                len[i] = nv[i] + nt[i];
-                vmax = std::max(vmax, nv[i]); rpb = std::max(rpb, len[i]);
+        if (!T.staged.empty()) {
+            // a pass beside the frame loop must have ended; an empty table has nothing else to do and waits for it
+            bool ready = true;
+            if (T.staged_side) {
+                if (T.occupied == 0) PTTS_HIP(hipEventSynchronize(T.staged_done));
+                const hipError_t q = hipEventQuery(T.staged_done);
+                if (q == hipErrorNotReady) { ready = false; (void)hipGetLastError(); }
+                else if (q != hipSuccess) PTTS_HIP(q);
             }
-            if (T.h_voice_rows < static_cast<size_t>(vmax)) {
-                if (T.h_voice) { PTTS_HIP(hipStreamSynchronize(st)); PTTS_HIP(hipHostFree(T.h_voice)); T.h_voice = nullptr; }
-                PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&T.h_voice), static_cast<size_t>(kSlots) * vmax * D * 4));
-                T.h_voice_rows = static_cast<size_t>(vmax);
-                pb.voice_stage.alloc(static_cast<size_t>(kSlots) * vmax * D * 4);
-            }
+            // one launch moves every row that can go now into its slot (KV rows, position, BOS row, start points); a second one,
+            // on the decoder stream behind whatever it still has queued for the slots' previous occupants, clears their
+            // decoder state (the reference zero-initialises every state tensor, :133-186)
             AdmitArgs aa;
-            bool any_noise = false;
-            for (int i = 0; i < k; ++i) {
-                const Request* r = incoming[i];
-                const Utterance& u = r->utt;
-                if (nv[i]) std::memcpy(T.h_voice + static_cast<size_t>(i) * vmax * D, u.voice, static_cast<size_t>(nv[i]) * D * 4);
-                std::memcpy(T.h_ids + static_cast<size_t>(i) * opt_.max_text_tokens, u.token_ids.data(), static_cast<size_t>(nt[i]) * 8);
-                // start points of frames 0..: explicit ones, drawn ones, or zeros (temperature 0, :606-613)
-                const float* nz = u.noise ? u.noise : (r->noise.empty() ? nullptr : r->noise.data());
-                aa.has_noise[i] = nz ? 1 : 0;
-                if (nz) { std::memcpy(T.h_noise + static_cast<size_t>(i) * F * L, nz, static_cast<size_t>(F) * L * 4); any_noise = true; }
-            }
-            PTTS_HIP(hipMemcpyAsync(pb.voice_stage.p, T.h_voice, static_cast<size_t>(k) * vmax * D * 4, hipMemcpyHostToDevice, st));
-            PTTS_HIP(hipMemcpyAsync(pb.ids_stage.p, T.h_ids, static_cast<size_t>(k) * opt_.max_text_tokens * 8, hipMemcpyHostToDevice, st));
-            if (any_noise) PTTS_HIP(hipMemcpyAsync(T.noise_stage.p, T.h_noise, static_cast<size_t>(k) * F * L * 4, hipMemcpyHostToDevice, st));
-            PTTS_HIP(hipMemcpyAsync(pb.st_nv.p, nv, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, st));
-            PTTS_HIP(hipMemcpyAsync(pb.st_nt.p, nt, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, st));
-            PTTS_HIP(hipMemcpyAsync(pb.st_len.p, len, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, st));
-            PTTS_HIP(hipMemsetAsync(pb.lm_pos.p, 0, pb.lm_pos.bytes, st));
-            std::fill(pb.lm_pos_host.begin(), pb.lm_pos_host.end(), 0);
-            pb.ensure_rows(static_cast<size_t>(k) * rpb, D, s.lm_ffn);
-            launch_assemble_prefill(pb.voice_stage.f(), static_cast<long long>(vmax) * D, pb.ids_stage.as<long long>(), opt_.max_text_tokens,
-                                    pb.st_nv.as<int>(), pb.st_nt.as<int>(), hd_.text_embed, s.vocab + 1, D, rpb, k, pb.x.f(), st);
-            lm_rows(pb, 0, k, rpb, pb.x.f(), pb.st_len.as<int>(), len);
-            // one launch moves every newcomer into its slot (KV rows, position, BOS row, start points); a second one, on the
-            // decoder stream behind whatever it still has queued for the slots' previous occupants, clears their decoder
-            // state (the reference zero-initialises every state tensor, :133-186)
-            int next_free = 0;
-            for (int i = 0; i < k; ++i) {
+            int k = 0, next_free = 0;
+            const bool empty = T.occupied == 0;
+            for (size_t j = 0; ready && j < T.staged.size() && T.occupied < kSlots; ++j) {
+                if (T.staged_in[j]) continue;
+                Request* r = T.staged[j];
+                // a stream joins at once while the table is lightly loaded (first-chunk latency; its chunks then fall on steps
+                // of their own and cost decoder calls of their own), on a chunk boundary of the clock once it is not; offline
+                // utterances join on multiples of the decoder chunk, so that one decoder call serves them all
+                const int period = r->streaming ? (T.occupied < kSlots / 4 ? 1 : std::min(r->chunk_frames, kDecChunk)) : kDecChunk;
+                if (!(empty || gs % period == 0)) continue;
                 while (T.slots[next_free].req) ++next_free;
                 Table::Slot& S = T.slots[next_free];
-                S.req = incoming[i]; S.g0 = gs; S.frames = 0; S.eos_step = -1; S.decoded = 0; S.generation += 1;
+                S.req = r; S.g0 = gs; S.frames = 0; S.eos_step = -1; S.decoded = 0; S.generation += 1;
                 ++T.occupied;
-                aa.slot[i] = static_cast<unsigned char>(next_free); aa.len[i] = len[i];
-                dr.slot[i] = static_cast<unsigned char>(next_free);
+                T.staged_in[j] = 1;
+                aa.slot[k] = static_cast<unsigned char>(next_free); aa.src[k] = static_cast<unsigned char>(j);
+                aa.len[k] = T.staged_len[j]; aa.has_noise[k] = T.staged_noise[j];
+                dr.slot[k] = static_cast<unsigned char>(next_free);
                 b.dec_pos_host[next_free] = 0;
+                ++k;
             }
-            aa.k = k; aa.layers = s.lm_layers; aa.row_bytes = static_cast<int>(D * kvb); aa.cap = b.lm_cap; aa.dst_slots = b.B; aa.src_slots = pb.B;
-            aa.k_dst = static_cast<char*>(b.lm_k.p); aa.v_dst = static_cast<char*>(b.lm_v.p);
-            aa.k_src = static_cast<const char*>(pb.lm_k.p); aa.v_src = static_cast<const char*>(pb.lm_v.p);
-            aa.lm_pos = b.lm_pos.as<int>(); aa.xcur = b.xcur.f(); aa.bos = bos_row_.f(); aa.L = L; aa.ring = R; aa.frames = F; aa.g0 = gs;
-            aa.noise_ring = b.noise_all.f(); aa.noise_stage = T.noise_stage.f();
-            launch_admit(aa, st);
-            dr.k = k;
-            launch_dec_reset(dr, dst);
-            check_launches("the admission");
-            std::lock_guard<std::mutex> lk(q_mu_);
-            sched_stats_.admissions += 1;
-            sched_stats_.utterances += k;
-            sched_stats_.largest = std::max(sched_stats_.largest, static_cast<long>(T.occupied));
+            if (k > 0) {
+                PTTS_TRACEF("step %d: %d admitted (%d in the table)", gs, k, T.occupied - k);
+                if (T.staged_side) PTTS_HIP(hipStreamWaitEvent(st, T.staged_done, 0));
+                aa.k = k; aa.layers = s.lm_layers; aa.row_bytes = static_cast<int>(D * kvb); aa.cap = b.lm_cap; aa.dst_slots = b.B; aa.src_slots = pb.B;
+                aa.k_dst = static_cast<char*>(b.lm_k.p); aa.v_dst = static_cast<char*>(b.lm_v.p);
+                aa.k_src = static_cast<const char*>(pb.lm_k.p); aa.v_src = static_cast<const char*>(pb.lm_v.p);
+                aa.lm_pos = b.lm_pos.as<int>(); aa.xcur = b.xcur.f(); aa.bos = bos_row_.f(); aa.L = L; aa.ring = R; aa.frames = F; aa.g0 = gs;
+                aa.noise_ring = b.noise_all.f(); aa.noise_stage = T.noise_stage.f();
+                launch_admit(aa, st);
+                PTTS_HIP(hipEventRecord(T.admit_done, st));
+                T.admit_pending = true;
+                dr.k = k;
+                launch_dec_reset(dr, dst);
+                check_launches("the admission");
+                std::lock_guard<std::mutex> lk(q_mu_);
+                sched_stats_.admissions += 1;
+                sched_stats_.utterances += k;
+                sched_stats_.largest = std::max(sched_stats_.largest, static_cast<long>(T.occupied));
+            }
         }
         if (T.occupied == 0) {
             std::lock_guard<std::mutex> lk(q_mu_);
-            if (queue_.empty()) break;
+            if (queue_.empty() && staged_left() == 0) break;
             continue;   // something queued that waits for a boundary of an empty table: cannot happen, but never spin on it
         }
         // ---- launch width: the occupied prefix, rounded up to a few sizes so that few graphs exist
