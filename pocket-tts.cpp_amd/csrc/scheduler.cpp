@@ -539,9 +539,13 @@ void Engine::run_table() {
         if (!T.staged.empty() && staged_left() == 0) { T.staged.clear(); T.staged_in.clear(); T.staged_len.clear(); T.staged_noise.clear(); T.staged_side = false; }
         if (T.staged.empty()) {
             std::vector<Request*> incoming;
-            const bool side = T.occupied > 0 && !sync_prefill;
+            bool side = T.occupied > 0 && !sync_prefill;
             {
                 std::unique_lock<std::mutex> lk(q_mu_);
+                // a stream that arrives at a lightly loaded table is prefilled in line after all: its first chunk matters more
+                // than the fraction of a millisecond that the few running slots wait for it
+                if (side && T.occupied < kSlots / 4)
+                    for (Request* r : queue_) if (r->streaming) { side = false; break; }
                 if (T.occupied == 0 && gather_us > 0) {
                     // an idle table waits a moment for the rest of a burst: callers that arrive together then share one prefill
                     // pass and one chunk phase instead of trailing each other by a step (POCKET_TTS_GATHER_US, default 100)
