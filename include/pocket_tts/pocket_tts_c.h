@@ -57,7 +57,8 @@ typedef struct {
 
 /* Streaming chunk sink (include/pocket_tts/pocket_tts_c.h:115-120).  `samples` is valid only for the
  * duration of the call.  is_final is 1 only on the tail chunk that flushes the frames left over after
- * generation stops (src/pocket_tts.cpp:897-965); see INTEGRATION.md for the multiple-of-chunk case. */
+ * generation stops (src/pocket_tts.cpp:897-965); when the frame count is a multiple of the chunk size nothing is left
+ * over and no chunk carries is_final = 1, as in the reference. */
 typedef void (*AudioChunkCallbackC)(const float* samples, int sample_count, int is_final, void* user_data);
 
 /* Streaming options, 16 bytes on LP64 (include/pocket_tts/pocket_tts_c.h:125-128). */
