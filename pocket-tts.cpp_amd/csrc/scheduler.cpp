@@ -65,10 +65,10 @@ struct Engine::Request {
 struct Engine::Table {
     struct Slot {
         Request* req = nullptr;
-        int g0 = 0, frames = 0, eos_step = -1, decoded = 0, generation = 0;
+        int g0 = 0, frames = 0, eos_step = -1, decoded = 0;
     };
-    struct Item { Request* req; int slot, f0, n; bool last_sub, is_final, latents; int lat_frames0, lat_g0; int parity; };
-    struct Delivery { hipEvent_t ev = nullptr; int slab = -1; int slot0 = 0, n = 0; std::vector<Item> items; };
+    struct Item { Request* req; int slot, f0, n; bool last_sub, is_final; };
+    struct Delivery { hipEvent_t ev = nullptr; int slab = -1; int slot0 = 0, n = 0; bool latents = false; std::vector<Item> items; };
 
     std::unique_ptr<Batch> b, pb;        // the table's state, and the staging batch prefill passes run in
     // Utterances whose prefill is in the staging batch (row i of it) and that wait for a slot or for their step of the clock.
@@ -83,7 +83,10 @@ struct Engine::Table {
     int occupied = 0;
     bool graphs_ready = false;
     float* slabs[kSlabs] = {};           // pinned [kSlots][15 * frame] PCM
-    float* h_lat[2] = {nullptr, nullptr};   // pinned [kSlots][lat_frames][L], by slot generation parity
+    float* lat_slabs[kSlabs] = {};       // pinned [kSlots][15][L]: the chunk's latent rows, for callers that asked for them
+    // dec_mark[m % 4] closes the decoder stream's work of steps <= 15 m + 14: the frame stream waits for the mark of two
+    // periods ago before it starts a period, so it never writes a row of the latent ring that a queued decoder call still reads
+    hipEvent_t dec_mark[4] = {};
     int* h_small = nullptr;                 // pinned [3][kSlots]: voice rows, tokens, lengths of the utterances being admitted
     // pinned staging of an admission's voice rows, token ids and start points (one upload each instead of one per utterance)
     float* h_voice = nullptr; size_t h_voice_rows = 0;
@@ -120,7 +123,8 @@ struct Engine::Table {
         }
         if (d_thread.joinable()) d_thread.join();
         for (auto& s : slabs) if (s) (void)hipHostFree(s);
-        for (auto& p : h_lat) if (p) (void)hipHostFree(p);
+        for (auto& p : lat_slabs) if (p) (void)hipHostFree(p);
+        for (auto& e : dec_mark) if (e) (void)hipEventDestroy(e);
         if (h_small) (void)hipHostFree(h_small);
         if (h_voice) (void)hipHostFree(h_voice);
         if (h_ids) (void)hipHostFree(h_ids);
@@ -170,11 +174,11 @@ void Engine::Table::deliver_main() {
                     }
                 }
             }
-            if (!err && it.latents) {
-                const float* hl = h_lat[it.parity] + static_cast<size_t>(it.slot) * R * L;
-                r->out->latents.resize(static_cast<size_t>(it.lat_frames0) * L);
-                for (int f = 0; f < it.lat_frames0; ++f)
-                    std::memcpy(r->out->latents.data() + static_cast<size_t>(f) * L, hl + static_cast<size_t>((it.lat_g0 + f) % R) * L, static_cast<size_t>(L) * 4);
+            if (!err && it.n > 0 && d.latents && r->want_latents) {
+                std::vector<float>& z = r->out->latents;
+                if (z.size() < static_cast<size_t>(it.f0 + it.n) * L) z.resize(static_cast<size_t>(it.f0 + it.n) * L);
+                std::memcpy(z.data() + static_cast<size_t>(it.f0) * L, lat_slabs[d.slab] + static_cast<size_t>(it.slot - d.slot0) * d.n * L,
+                            static_cast<size_t>(it.n) * L * 4);
             }
             if (err) {
                 // the request fails once, at its last item; its earlier items are dropped
@@ -432,7 +436,8 @@ void Engine::run_table() {
         N.pb = std::make_unique<Batch>(*this, kSlots, true);
         N.fs = fs; N.R = N.b->lat_frames; N.L = L; N.F = opt_.max_frames; N.device = opt_.device;
         for (auto& p : N.slabs) PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), static_cast<size_t>(kSlots) * kDecChunk * fs * 4));
-        for (auto& p : N.h_lat) PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), static_cast<size_t>(kSlots) * N.R * L * 4));
+        for (auto& p : N.lat_slabs) PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), static_cast<size_t>(kSlots) * kDecChunk * L * 4));
+        for (auto& e : N.dec_mark) PTTS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         N.b->noise_all.alloc(static_cast<size_t>(kSlots) * N.R * L * 4);
         N.noise_stage.alloc(static_cast<size_t>(kSlots) * F * L * 4);
         PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&N.h_small), static_cast<size_t>(3) * kSlots * 4));
@@ -651,7 +656,7 @@ void Engine::run_table() {
                 if (!(empty || gs % period == 0)) continue;
                 while (T.slots[next_free].req) ++next_free;
                 Table::Slot& S = T.slots[next_free];
-                S.req = r; S.g0 = gs; S.frames = 0; S.eos_step = -1; S.decoded = 0; S.generation += 1;
+                S.req = r; S.g0 = gs; S.frames = 0; S.eos_step = -1; S.decoded = 0;
                 ++T.occupied;
                 T.staged_in[j] = 1;
                 aa.slot[k] = static_cast<unsigned char>(next_free); aa.src[k] = static_cast<unsigned char>(j);
@@ -695,6 +700,10 @@ void Engine::run_table() {
         // slots that step without an utterance restart at position 0 now and then, so that they never leave their cache
         if (idle_mask && gs % 8 == 0) launch_reset_pos_mask(b.lm_pos.as<int>(), idle_mask, st);
         if (b.Bw != width) b.Bw = width;
+        // Step gs writes the ring row of step gs - R.  Whatever reads that row on the decoder stream was issued by step
+        // gs - R + max_frames - 1 at the latest (a chunk is never longer than an utterance), and R - max_frames >= 30: the
+        // mark recorded at step gs - 16 covers it for this whole period of 15 steps.
+        if (gs % kDecChunk == 0 && gs >= 2 * kDecChunk) PTTS_HIP(hipStreamWaitEvent(st, T.dec_mark[(gs / kDecChunk - 2) % 4], 0));
         if (graph) {
             hipGraphExec_t* exec = ensure_frame_graph(b);
             PTTS_HIP(hipGraphLaunch(exec[gs & 1], st));
@@ -706,7 +715,7 @@ void Engine::run_table() {
         wait_flag(b.h_flag, gs + 1, st, flag_wait);
         gpu.lock();
         const float* e_now = b.h_eos_all + static_cast<size_t>(gs % b.eos_ring) * b.B;
-        struct Due { Request* req; int slot, n, f0, gstart; bool last_sub, is_final, closes; int g0, generation; };
+        struct Due { Request* req; int slot, n, f0, gstart; bool last_sub, is_final, closes; };
         std::vector<Due> due;
         long frames_now = 0;
         for (int i = 0; i < width; ++i) {
@@ -743,18 +752,18 @@ void Engine::run_table() {
                     const bool tail = pending < r->chunk_frames;
                     for (int f0 = 0; f0 < pending; f0 += kDecChunk) {                          // sub-chunks of <= 15 frames (:796)
                         const int n = std::min(kDecChunk, pending - f0);
-                        due.push_back({r, i, n, S.decoded + f0, S.g0 + S.decoded + f0, f0 + n == pending, tail, false, S.g0, S.generation});
+                        due.push_back({r, i, n, S.decoded + f0, S.g0 + S.decoded + f0, f0 + n == pending, tail, false});
                     }
                     S.decoded = S.frames;
                 }
             } else if (pending > 0 && (stop || pending == kDecChunk)) {
-                due.push_back({r, i, pending, S.decoded, S.g0 + S.decoded, true, false, false, S.g0, S.generation});
+                due.push_back({r, i, pending, S.decoded, S.g0 + S.decoded, true, false, false});
                 S.decoded = S.frames;
             }
             if (stop) {
                 r->out->frames = S.frames;
                 // nothing left to decode: the request closes through an item without audio (ordered behind its earlier chunks)
-                if (due.size() == first_due) due.push_back({r, i, 0, S.frames, gs + 1, true, false, false, S.g0, S.generation});
+                if (due.size() == first_due) due.push_back({r, i, 0, S.frames, gs + 1, true, false, false});
                 due.back().closes = true;
                 // every item of the request is counted before it is marked closed: the delivery thread finishes a closed
                 // request when the count reaches zero
@@ -800,19 +809,24 @@ void Engine::run_table() {
                     mimi_decode_dev(b, nullptr, 0, n, chunk, static_cast<long long>(kDecChunk) * fs, dst, lo, hi - lo + 1, due[a0].gstart % R, mask);
                     PTTS_HIP(hipMemcpy2DAsync(T.slabs[dv.slab], static_cast<size_t>(n) * fs * 4, chunk, static_cast<size_t>(kDecChunk) * fs * 4,
                                               static_cast<size_t>(n) * fs * 4, hi - lo + 1, hipMemcpyDeviceToHost, dst));
+                    for (size_t j = a0; j < a1; ++j) dv.latents = dv.latents || due[j].req->want_latents;
+                    if (dv.latents) {
+                        // the chunk's rows of the latent ring (in two pieces where the chunk runs over the end of the ring)
+                        const int r0 = due[a0].gstart % R, n1 = std::min(n, R - r0);
+                        const float* ring = b.latents.f() + static_cast<size_t>(lo) * R * L;
+                        PTTS_HIP(hipMemcpy2DAsync(T.lat_slabs[dv.slab], static_cast<size_t>(n) * L * 4, ring + static_cast<size_t>(r0) * L,
+                                                  static_cast<size_t>(R) * L * 4, static_cast<size_t>(n1) * L * 4, hi - lo + 1, hipMemcpyDeviceToHost, dst));
+                        if (n1 < n)
+                            PTTS_HIP(hipMemcpy2DAsync(T.lat_slabs[dv.slab] + static_cast<size_t>(n1) * L, static_cast<size_t>(n) * L * 4, ring,
+                                                      static_cast<size_t>(R) * L * 4, static_cast<size_t>(n - n1) * L * 4, hi - lo + 1,
+                                                      hipMemcpyDeviceToHost, dst));
+                    }
                     std::lock_guard<std::mutex> lk(q_mu_);
                     sched_stats_.decode_calls += 1;
                 }
                 for (size_t j = a0; j < a1; ++j) {
                     const Due& q = due[j];
-                    Table::Item it{q.req, q.slot, q.f0, q.n, q.last_sub, q.is_final, false, 0, 0, q.generation & 1};
-                    if (q.closes && q.req->want_latents) {
-                        // the slot's whole latent ring; the rows of this utterance are picked out when the copy has landed
-                        it.latents = true; it.lat_frames0 = q.req->out->frames; it.lat_g0 = q.g0;
-                        PTTS_HIP(hipMemcpyAsync(T.h_lat[it.parity] + static_cast<size_t>(q.slot) * R * L, b.latents.f() + static_cast<size_t>(q.slot) * R * L,
-                                                static_cast<size_t>(R) * L * 4, hipMemcpyDeviceToHost, dst));
-                    }
-                    dv.items.push_back(it);
+                    dv.items.push_back(Table::Item{q.req, q.slot, q.f0, q.n, q.last_sub, q.is_final});
                 }
                 dv.ev = get_event();
                 PTTS_HIP(hipEventRecord(dv.ev, dst));
@@ -827,6 +841,7 @@ void Engine::run_table() {
             }
             T.due_reqs.clear(); T.due_pushed = 0;
         }
+        if (gs % kDecChunk == kDecChunk - 1) PTTS_HIP(hipEventRecord(T.dec_mark[(gs / kDecChunk) % 4], dst));
         ++gs;
     }
     // ---- the table is empty: everything still in flight lands, then the activation ends
