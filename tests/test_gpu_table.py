@@ -303,3 +303,29 @@ def test_more_callers_than_slots_mixed_traffic(packs):
     again = eng.generate_ids([ids[0]], [voices[0]], want_latents=False)[0]
     assert again["frames"] == frames[0]
     eng.close()
+
+
+def test_latents_of_chunks_that_run_over_the_end_of_the_ring(packs, oracle_mod):
+    """Four tables' worth of utterances that all run to max_frames = 25: every wave joins the moment the table is empty,
+    at steps 0, 25, 50 and 75 of the clock, and the per-slot latent ring has 60 rows, so the third wave's first decoder
+    chunk covers ring rows 50..59 and 0..4.  Latents, EOS logits and audio of every utterance against the oracle."""
+    import ptts_lib as ptts
+    path, spec, _ = packs["tiny"]
+    F, N = 25, 256
+    eng = ptts.Engine(path, precision="fp32", temperature=0.0, lsd_steps=4, max_frames=F)
+    o = oracle_mod.Oracle(path)
+    rng = np.random.default_rng(77)
+    ids, voices = _ragged(spec, rng, N)
+    res = eng.generate_ids(ids, voices, queued=True)
+    st = eng.scheduler_stats()
+    worst = 0.0
+    for i in range(N):
+        lat, eos, frames = oracle_replay(o, ids[i], voices[i], res[i]["latents"], 4, F)
+        assert res[i]["frames"] == frames == F, (i, res[i]["frames"], frames)
+        assert res[i]["latents"].shape[0] == F
+        worst = max(worst, float(np.abs(res[i]["eos"] - eos).max()), float(np.abs(res[i]["latents"] - lat).max()))
+    assert worst < 1e-3
+    for i in (0, 63, 64, 128, 129, 191, 192, N - 1):
+        assert snr_db(oracle_decode(o, res[i]["latents"]), res[i]["audio"]) >= 40.0, i
+    assert st["frame_steps"] == 4 * F, st   # no step of the clock was spent waiting for a chunk boundary
+    eng.close()
