@@ -594,151 +594,6 @@ void launch_add_norm(const AddNormArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL(add_norm_kernel<16>, grid, block, 0, s, a);
 }
 
-// ------------------------------------------------------------------ add & norm inside the consuming product
-// 16 rows x 64 columns per workgroup of 16 waves, K = D <= 1024 whole, D % 128 == 0.  Wave w forms row w of the tile (one
-// round trip for the whole tile): lane l owns channels 256 i + 4 l .. + 3, i < 4, which are the channels thread 64 i + l owns
-// in add_norm_kernel, and sums are taken wave-chunk by wave-chunk like there, so the row is bitwise the one that kernel
-// writes; the normalised row goes to LDS as hi + lo bf16 terms.  For the product wave w owns column tile w % 4 and the
-// quarter w / 4 of K: its D / 128 weight fragments are requested before anything else and held in registers, the four
-// quarters of a tile meet in LDS and are added in order.
-template <int MAXS>
-__global__ __launch_bounds__(1024) void norm_gemm_kernel(NormGemmArgs a) {
-    constexpr int KQMAX = 8, ROWS = 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char ng_smem[];
-    const int LDA = a.D + 8;
-    __bf16* hi_p = (__bf16*)ng_smem;
-    __bf16* lo_p = hi_p + ROWS * LDA;
-    float* red = (float*)(lo_p + ROWS * LDA);   // [16 waves][64 lanes][4]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ct = wave & 3, kq = wave >> 2;
-    const int nt = blockIdx.x * 4 + ct;
-    const bool tile_live = nt * 16 < a.N;
-    const int m0 = blockIdx.y * ROWS;
-    const int KS = a.D / 32, KQ = KS / 4;
-    // no load of this kernel sits behind a condition (a conditional load becomes a branch with a wait of its own): addresses
-    // are clamped to something valid instead, and what must not count is replaced after it has arrived
-    const uint4* wbase = (const uint4*)a.Wp + ((long long)(tile_live ? nt : 0) * KS + (long long)kq * KQ) * 64 + lane;
-    uint4 breg[KQMAX];
-#pragma unroll
-    for (int ks = 0; ks < KQMAX; ++ks) breg[ks] = wbase[(long long)(ks < KQ ? ks : KQ - 1) * 64];
-
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool on[4];
-    int cc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = 256 * i + 4 * lane;
-        on[i] = c < a.D;
-        cc[i] = on[i] ? c : 0;
-    }
-    const float* slabs = a.P ? a.P : a.Xin;   // without K-slices the loads below re-read the row and their values are dropped
-    const int nsl = a.P ? a.splits : 0;
-    const long long slab_stride = a.P ? (long long)a.M * a.D : 0;
-    const int slab_ld = a.P ? a.D : a.ldx;
-    const int lr = wave, m = m0 + lr;
-    const bool row_on = m < a.M;
-    const int mm = row_on ? m : a.M - 1;
-    float4 v[4], part[MAXS][4], s4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = *(const float4*)(a.Xin + (long long)mm * a.ldx + cc[i]);
-#pragma unroll
-    for (int k = 0; k < MAXS; ++k) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) part[k][i] = *(const float4*)(slabs + (k < nsl ? k : 0) * slab_stride + (long long)mm * slab_ld + cc[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s4[i] = *(const float4*)((a.colscale ? a.colscale : a.g) + cc[i]);
-    float sm[4], sq[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (!a.colscale) s4[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (!on[i]) v[i] = zero;
-        float4 p = zero;
-#pragma unroll
-        for (int k = 0; k < MAXS; ++k) {
-            if (k < nsl) { p.x += part[k][i].x; p.y += part[k][i].y; p.z += part[k][i].z; p.w += part[k][i].w; }
-        }
-        if (a.P && on[i]) {
-            p.x *= s4[i].x; p.y *= s4[i].y; p.z *= s4[i].z; p.w *= s4[i].w;
-            v[i].x += p.x; v[i].y += p.y; v[i].z += p.z; v[i].w += p.w;
-        }
-        sm[i] = wsum64((v[i].x + v[i].y) + (v[i].z + v[i].w));
-    }
-    // the slab registers are free now: scale and shift of the normalisation arrive while the statistics are formed
-    float4 g4[4], b4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { g4[i] = *(const float4*)(a.g + cc[i]); b4[i] = *(const float4*)(a.b + cc[i]); }
-    if (blockIdx.x == 0 && a.Xout && row_on) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (on[i]) *(float4*)(a.Xout + (long long)m * a.ldx + cc[i]) = v[i];
-    }
-    const float mean = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / (float)a.D;
-    float4 d[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        d[i] = on[i] ? make_float4(v[i].x - mean, v[i].y - mean, v[i].z - mean, v[i].w - mean) : zero;
-        sq[i] = wsum64((d[i].x * d[i].x + d[i].y * d[i].y) + (d[i].z * d[i].z + d[i].w * d[i].w));
-    }
-    const float rstd = 1.0f / sqrtf(((sq[0] + sq[1]) + (sq[2] + sq[3])) / (float)a.D + a.eps);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (!on[i]) continue;
-        float4 y = make_float4(d[i].x * rstd * g4[i].x + b4[i].x, d[i].y * rstd * g4[i].y + b4[i].y,
-                               d[i].z * rstd * g4[i].z + b4[i].z, d[i].w * rstd * g4[i].w + b4[i].w);
-        if (!row_on) y = zero;
-        bf16x4 h4, l4;
-        split_bf16(y, h4, l4);
-        *(bf16x4*)(hi_p + lr * LDA + cc[i]) = h4;
-        *(bf16x4*)(lo_p + lr * LDA + cc[i]) = l4;
-    }
-    __syncthreads();
-    const int r = lane & 15, g = lane >> 4;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int k0 = kq * KQ * 32;
-#pragma unroll
-    for (int ks = 0; ks < KQMAX; ++ks) {
-        if (ks < KQ) {
-            const bf16x8 b8 = __builtin_bit_cast(bf16x8, breg[ks]);
-            const bf16x8 lo8 = *(const bf16x8*)(lo_p + r * LDA + k0 + ks * 32 + 8 * g);
-            const bf16x8 hi8 = *(const bf16x8*)(hi_p + r * LDA + k0 + ks * 32 + 8 * g);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo8, b8, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi8, b8, acc, 0, 0, 0);
-        }
-    }
-    *(f32x4*)(red + ((size_t)wave * 64 + lane) * 4) = acc;
-    __syncthreads();
-    if (kq != 0 || !tile_live) return;
-    const float* bias_p = a.bias ? a.bias : a.g;
-    float bias_col = bias_p[nt * 16 + r];
-    if (!a.bias) bias_col = 0.f;
-    f32x4 t = acc;
-#pragma unroll
-    for (int q = 1; q < 4; ++q) {
-        const f32x4 o = *(const f32x4*)(red + ((size_t)(q * 4 + ct) * 64 + lane) * 4);
-        t[0] += o[0]; t[1] += o[1]; t[2] += o[2]; t[3] += o[3];
-    }
-    const int col = nt * 16 + r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = m0 + g * 4 + i;
-        if (row >= a.M) continue;
-        a.C[(long long)row * a.ldc + col] = act_dev(t[i] + bias_col, a.act);
-    }
-}
-
-void launch_norm_gemm(const NormGemmArgs& a, hipStream_t s) {
-    if (a.M <= 0) return;
-    if (a.D % 128 || a.D > 1024 || a.N % 16 || (a.ldx & 3) || !a.g || !a.b || !a.Xin || !a.C || !a.Wp || a.pbias)
-        throw std::runtime_error("norm gemm: needs D % 128 == 0, D <= 1024, N % 16 == 0, a normalisation and no slab bias");
-    if (a.Xout == a.Xin) throw std::runtime_error("norm gemm: the updated rows need a buffer of their own");
-    if (a.P && (a.splits < 1 || a.splits > 8)) throw std::runtime_error("norm gemm: 1..8 K-slices supported");
-    const size_t smem = (size_t)2 * 16 * (a.D + 8) * 2 + (size_t)16 * 64 * 16;
-    dim3 grid((a.N + 63) / 64, (a.M + 15) / 16), block(1024);
-    if (a.P && a.splits > 4) hipLaunchKernelGGL(norm_gemm_kernel<8>, grid, block, smem, s, a);
-    else hipLaunchKernelGGL(norm_gemm_kernel<4>, grid, block, smem, s, a);
-}
-
 // ------------------------------------------------------------------ decode attention, one 4-wave block per (row, head)
 // The earlier keys of the slot are cut into four contiguous ranges, one per wave (the step is latency
 // bound, so more independent loads in flight matter more than work per wave).  Each wave runs local

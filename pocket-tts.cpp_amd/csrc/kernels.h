@@ -280,23 +280,6 @@ struct AddNormArgs {
 };
 void launch_add_norm(const AddNormArgs& a, hipStream_t s);
 
-// Add & norm folded into the matrix product that consumes it (bf16 weights, D <= 1024, D % 32 == 0): every workgroup (16 rows x
-// 64 output columns) forms its rows x = Xin + colscale * (sum_s P[s] + pbias) and y = LayerNorm(x; g, b) itself, with the sums
-// taken in the order add_norm_kernel takes them (bitwise the same y), keeps y as two bf16 terms in LDS and multiplies it with
-// its weight columns, which it requested before anything else: C = act(y W^T + bias).  The workgroups of column group 0 also
-// write x to Xout, which must not be Xin (the other column groups are still reading it).
-struct NormGemmArgs {
-    const float* Xin = nullptr; float* Xout = nullptr; int ldx = 0;
-    const float* P = nullptr; int splits = 0;
-    const float* colscale = nullptr; const float* pbias = nullptr;
-    const float* g = nullptr; const float* b = nullptr; float eps = 1e-5f;
-    const void* Wp = nullptr;          // fragment-major bf16 [N / 16][D / 32][64 lanes x 16 bytes]
-    int M = 0, N = 0, D = 0;
-    const float* bias = nullptr; int act = ACT_NONE;
-    float* C = nullptr; int ldc = 0;
-};
-void launch_norm_gemm(const NormGemmArgs& a, hipStream_t s);
-
 // One new token per row: rotate q/k of qkv[M][3d] at position pos[m], append k/v to slot slot0+m of the
 // cache, attend over the slot's keys (window as in AttentionArgs), write out[M][d].
 struct AttnDecodeArgs {

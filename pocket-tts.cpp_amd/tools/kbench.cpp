@@ -126,55 +126,6 @@ static void bench_skinny_q8p(const char* name, int M, int N, int K, int splits, 
     time_it(name, 300, [&](hipStream_t s) { launch_skinny_gemm(a, s); }, (double)N * K + (double)M * K + (double)M * N * 4 * splits, 2.0 * M * N * K);
 }
 
-// add & norm + product as two launches against the folded form: same inputs, results compared bit for bit, both timed
-static void bench_norm_gemm(const char* name, int M, int N, int D, int slabs, int act, int qkv_splits) {
-    float* X = (float*)dalloc((size_t)M * D * 4);
-    float* X0 = (float*)dalloc((size_t)M * D * 4);
-    float* X2 = (float*)dalloc((size_t)M * D * 4, 0);
-    float* P = (float*)dalloc((size_t)slabs * M * D * 4);
-    float* H = (float*)dalloc((size_t)M * D * 4, 0);
-    const float* ls = (const float*)dalloc((size_t)D * 4);
-    const float* g = (const float*)dalloc((size_t)D * 4);
-    const float* bb = (const float*)dalloc((size_t)D * 4);
-    void* W = packed_weight(N, D, W_BF16);
-    float* C1 = (float*)dalloc((size_t)std::max(1, qkv_splits) * M * N * 4, 0);
-    float* C2 = (float*)dalloc((size_t)M * N * 4, 0);
-    AddNormArgs an;
-    an.X = X; an.ldx = D; an.M = M; an.D = D; an.P = P; an.splits = slabs; an.colscale = ls; an.g = g; an.b = bb; an.H = H;
-    SkinnyArgs sk;
-    sk.A = H; sk.lda = D; sk.Wp = W; sk.wtype = W_BF16; sk.M = M; sk.N = N; sk.K = D; sk.act = act;
-    if (qkv_splits > 1) { sk.splits = qkv_splits; sk.P = C1; } else { sk.C = C1; sk.ldc = N; }
-    NormGemmArgs ng;
-    ng.Xin = X0; ng.Xout = X2; ng.ldx = D; ng.P = P; ng.splits = slabs; ng.colscale = ls; ng.g = g; ng.b = bb;
-    ng.Wp = W; ng.M = M; ng.N = N; ng.D = D; ng.act = act; ng.C = C2; ng.ldc = N;
-    CK(hipMemcpy(X, X0, (size_t)M * D * 4, hipMemcpyDeviceToDevice));
-    launch_add_norm(an, 0);
-    launch_skinny_gemm(sk, 0);
-    launch_norm_gemm(ng, 0);
-    CK(hipDeviceSynchronize());
-    std::vector<float> c1((size_t)std::max(1, qkv_splits) * M * N), c2((size_t)M * N), x1((size_t)M * D), x2((size_t)M * D);
-    CK(hipMemcpy(c1.data(), C1, c1.size() * 4, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(c2.data(), C2, c2.size() * 4, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(x1.data(), X, x1.size() * 4, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(x2.data(), X2, x2.size() * 4, hipMemcpyDeviceToHost));
-    size_t dc = 0, dx = 0;
-    double worst = 0;
-    for (size_t i = 0; i < c2.size(); ++i) {
-        float ref = c1[i];
-        for (int sidx = 1; sidx < qkv_splits; ++sidx) ref += c1[(size_t)sidx * M * N + i];
-        dc += ref != c2[i];
-        worst = std::max(worst, (double)std::fabs(ref - c2[i]));
-    }
-    for (size_t i = 0; i < x2.size(); ++i) dx += x1[i] != x2[i];
-    std::printf("%s: folded against two launches: %zu of %zu results differ (max-abs %.3e), %zu of %zu residual values differ\n", name, dc, c2.size(),
-                worst, dx, x2.size());
-    char nm[64];
-    std::snprintf(nm, sizeof nm, "%s_2launch", name);
-    time_it(nm, 300, [&](hipStream_t s) { launch_add_norm(an, s); launch_skinny_gemm(sk, s); }, (double)N * D * 2, 2.0 * M * N * D);
-    std::snprintf(nm, sizeof nm, "%s_folded", name);
-    time_it(nm, 300, [&](hipStream_t s) { launch_norm_gemm(ng, s); }, (double)N * D * 2, 2.0 * M * N * D);
-}
-
 static void bench_gemm(const char* name, int M, int N, int K, int split_a, int lda = 0) {
     GemmArgs g;
     if (!lda) lda = K;
@@ -308,15 +259,6 @@ int main(int argc, char** argv) {
     if (want("skinny_ff1")) bench_skinny("skinny_ff1", 64, 4096, 1024, 1);
     if (want("skinny_out")) bench_skinny("skinny_out", 64, 1024, 1024, 4);
     if (want("skinny_ff2")) bench_skinny("skinny_ff2", 64, 1024, 4096, 16);
-    if (want("norm_ff1")) bench_norm_gemm("norm_ff1", 64, 4096, 1024, 4, ACT_GELU, 1);
-    if (want("norm_qkv")) bench_norm_gemm("norm_qkv", 64, 3072, 1024, 8, ACT_NONE, 4);
-    if (want("norm_qkv4")) bench_norm_gemm("norm_qkv4", 64, 3072, 1024, 4, ACT_NONE, 4);
-    if (want("norm_probe")) {
-        bench_norm_gemm("norm_ff1_1slab", 64, 4096, 1024, 1, ACT_GELU, 1);
-        bench_norm_gemm("norm_ff1_64cols", 64, 64, 1024, 4, ACT_GELU, 1);
-        bench_norm_gemm("norm_ff1_512cols", 64, 512, 1024, 4, ACT_GELU, 1);
-        bench_norm_gemm("norm_ff1_16rows", 16, 4096, 1024, 4, ACT_GELU, 1);
-    }
     if (want("skinny_q8_qkv")) bench_skinny_q8("skinny_q8_qkv", 64, 3072, 1024, 1);
     if (want("skinny_q8_ff2")) bench_skinny_q8("skinny_q8_ff2", 64, 1024, 4096, 16);
     if (want("gemm_ada")) bench_gemm("gemm_ada", 640, 10240, 512, 1);
