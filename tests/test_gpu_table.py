@@ -8,6 +8,7 @@
 
 The reference serves one utterance per call (src/pocket_tts.cpp:548-657, :686-979); the table's per-utterance results
 are checked against exactly that behaviour, restated by the oracle."""
+import os
 import threading
 
 import numpy as np
@@ -16,6 +17,11 @@ import pytest
 from conftest import oracle_decode, oracle_replay, snr_db
 
 pytestmark = pytest.mark.gpu
+
+# two of the tests below state what ONE table does (its largest occupancy; first-chunk latency with the persistent flow head,
+# which only the first engine on a GPU holds): they are skipped when the environment asks for several engines per GPU
+one_engine = pytest.mark.skipif(os.environ.get("POCKET_TTS_ENGINES_PER_GPU", "1") not in ("", "1"),
+                                reason="states the behaviour of a single table; POCKET_TTS_ENGINES_PER_GPU asks for several")
 
 
 def _note(line):
@@ -103,6 +109,7 @@ def full_pack(tmp_path_factory):
     return path, spec
 
 
+@one_engine
 def test_eight_concurrent_streams_first_chunk_latency(full_pack):
     """Full-size model, bf16, chunk of 5 frames.  One caller alone, then eight threads at once on the same handle: each
     stream's first chunk must arrive within twice the single caller's latency (the streams ride one table instead of
@@ -239,6 +246,7 @@ def test_two_engines_behind_one_handle(packs, oracle_mod, monkeypatch):
     eng.close()
 
 
+@one_engine
 def test_more_callers_than_slots_mixed_traffic(packs):
     """96 threads on one handle at once, more than the table has slots: streams with chunk sizes 1 to 20, single offline calls
     and a few queued batches.  Every call returns (the test's time limit is the deadlock detector), chunks arrive in the
