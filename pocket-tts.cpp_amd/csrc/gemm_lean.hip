@@ -9,6 +9,8 @@
 // A is rounded to bf16 once while staged, or (SPLIT) carried as two bf16 terms.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "kernels.h"
@@ -36,15 +38,30 @@ constexpr int LBM = 128, LBN = 128, LBK = 64, LLD = LBK + 8;
 // meets both, so the product carries the activation to ~16 mantissa bits (the latent path's prefill).
 // WSPLIT (with SPLIT): the weights come as two bf16 terms as well (a.W, a.W2); the third MFMA adds A_hi W_lo.
 template <bool ABF, bool CBF, bool SPLIT, bool WSPLIT = false>
-__global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a, int gw) {
     __shared__ __attribute__((aligned(16))) __bf16 As[LBM * LLD];
     __shared__ __attribute__((aligned(16))) __bf16 Al[SPLIT ? LBM * LLD : 8];
     __shared__ __attribute__((aligned(16))) __bf16 Ws[LBN * LLD];
     __shared__ __attribute__((aligned(16))) __bf16 Wl[WSPLIT ? LBN * LLD : 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * LBM, n0 = blockIdx.y * LBN;
     const int M = a.M, N = a.N, K = a.K;
+    // Tile of this workgroup.  gw == 0: blockIdx (x, y) = (m tile, n tile).  gw > 0: a one-dimensional grid laid out for
+    // the eight XCDs, each with an L2 of its own: workgroup L is dispatched to XCD L % 8, so the sequence L / 8 is what
+    // one XCD sees in order.  That sequence walks groups of gw n tiles (weights of a group stay in the XCD's L2) and,
+    // inside a group, every n tile of an m tile before the next m tile: the re-reads of an A tile come from the workgroups
+    // that follow each other on the same XCD and hit its L2 instead of going out to the fabric.
+    int mt = blockIdx.x, nt = blockIdx.y;
+    if (gw > 0) {
+        const int MT = (M + LBM - 1) / LBM, NT = (N + LBN - 1) / LBN, MT8 = (MT + 7) >> 3;
+        const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+        const int g = s / (MT8 * gw), r = s - g * (MT8 * gw);
+        const int width = min(gw, NT - g * gw);
+        mt = (r / width) * 8 + xcd;
+        nt = g * gw + r % width;
+        if (mt >= MT) return;
+    }
+    const int m0 = mt * LBM, n0 = nt * LBN;
 
     // ---- staging assignment: A as 16 (f32) or 8 (bf16) pieces per row of a K step, W as 8 pieces per row
     constexpr int APR = ABF ? 8 : 16, APT = LBM * APR / 256;     // pieces per row, pieces per thread
@@ -236,17 +253,24 @@ bool gemm_lean_eligible(const GemmArgs& a) {
 }
 
 void launch_gemm_lean(const GemmArgs& a, hipStream_t s) {
-    dim3 grid((a.M + LBM - 1) / LBM, (a.N + LBN - 1) / LBN), block(256);
+    static const int xcd_map = [] { const char* e = std::getenv("POCKET_TTS_GEMM_XCD_MAP"); return e ? std::atoi(e) : 1; }();
+    const int MT = (a.M + LBM - 1) / LBM, NT = (a.N + LBN - 1) / LBN;
+    // n tiles per group: about 2 MiB of bf16 weights (half of one XCD's L2), at least 2
+    int gw = 0;
+    // (an XCD takes whole m tiles: with few m tiles that are not a multiple of 8 some XCDs would get a tile less or none)
+    if (xcd_map && NT > 1 && (((MT + 7) / 8) * 8 - MT) * 16 <= MT) gw = std::min(NT, std::max(2, (2 << 20) / (LBN * a.K * 2 * (a.W2 ? 2 : 1))));
+    dim3 grid(MT, NT), block(256);
+    if (gw) grid = dim3(((MT + 7) / 8) * 8 * NT, 1);
     if (a.split_a && a.W2) {
-        hipLaunchKernelGGL((gemm_lean_kernel<false, false, true, true>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((gemm_lean_kernel<false, false, true, true>), grid, block, 0, s, a, gw);
     } else if (a.split_a) {
-        hipLaunchKernelGGL((gemm_lean_kernel<false, false, true>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((gemm_lean_kernel<false, false, true>), grid, block, 0, s, a, gw);
     } else if (a.a_bf16) {
-        if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<true, true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_lean_kernel<true, false, false>), grid, block, 0, s, a);
+        if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<true, true, false>), grid, block, 0, s, a, gw);
+        else hipLaunchKernelGGL((gemm_lean_kernel<true, false, false>), grid, block, 0, s, a, gw);
     } else {
-        if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<false, true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_lean_kernel<false, false, false>), grid, block, 0, s, a);
+        if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<false, true, false>), grid, block, 0, s, a, gw);
+        else hipLaunchKernelGGL((gemm_lean_kernel<false, false, false>), grid, block, 0, s, a, gw);
     }
 }
 
