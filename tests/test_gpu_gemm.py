@@ -1,6 +1,6 @@
 """The bf16-weight GEMM dispatch at shapes and options the model paths do not all visit: tile tails in M, N and K,
-every epilogue option of the lean kernel, bf16 rows in and out, the two-term A form, and shapes that fall back to
-the general kernel.  Reference: numpy on the same bf16-rounded operands, float64 accumulation."""
+every epilogue option of the lean kernel, its XCD tile order with ragged tile counts, bf16 rows in and out, the two-term
+A form, and shapes that fall back to the general kernel.  Reference: numpy on the same bf16-rounded operands, float64 accumulation."""
 import numpy as np
 import pytest
 
@@ -41,6 +41,8 @@ CASES = [
     (700, 64, 128, True, False, False, 3, False, False, True),        # lean: bf16 rows out only
     (96, 64, 128, True, False, False, 0, False, True, True),          # small M with bf16 rows: still the lean kernel
     (1500, 384, 1024, False, True, True, 0, True, False, False),      # lean, two-term A
+    (15400, 1160, 1024, True, False, True, 0, False, False, False),   # lean, XCD tile order: 121 m tiles (the last XCDs get one less), n tiles in groups of 8 + 2
+    (2048, 300, 4096, False, False, False, 0, True, False, False),    # lean, XCD tile order, two-term A: n tiles in groups of 2 + 1
     (200, 96, 64, True, False, True, 2, False, False, False),         # general kernel (small M)
     (64, 1024, 32, False, False, False, 0, True, False, False),       # general kernel, two-term A
 ]
