@@ -37,8 +37,9 @@ constexpr int LBM = 128, LBN = 128, LBK = 64, LLD = LBK + 8;
 // SPLIT (f32 A only): A is staged as two bf16 terms, hi = bf16(a) and lo = bf16(a - hi), and every weight fragment
 // meets both, so the product carries the activation to ~16 mantissa bits (the latent path's prefill).
 // WSPLIT (with SPLIT): the weights come as two bf16 terms as well (a.W, a.W2); the third MFMA adds A_hi W_lo.
-template <bool ABF, bool CBF, bool SPLIT, bool WSPLIT = false>
-__global__ __launch_bounds__(256) void gemm_lean_kernel(GemmArgs a, int gw) {
+// OCC: workgroups per CU the register allocation is held to (3: 168 registers per lane)
+template <bool ABF, bool CBF, bool SPLIT, bool WSPLIT = false, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void gemm_lean_kernel(GemmArgs a, int gw) {
     __shared__ __attribute__((aligned(16))) __bf16 As[LBM * LLD];
     __shared__ __attribute__((aligned(16))) __bf16 Al[SPLIT ? LBM * LLD : 8];
     __shared__ __attribute__((aligned(16))) __bf16 Ws[LBN * LLD];
@@ -269,6 +270,13 @@ void launch_gemm_lean(const GemmArgs& a, hipStream_t s) {
         if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<true, true, false>), grid, block, 0, s, a, gw);
         else hipLaunchKernelGGL((gemm_lean_kernel<true, false, false>), grid, block, 0, s, a, gw);
     } else {
+        // f32 rows in, K of at most 1024: three workgroups per CU (168 registers, 28 bytes of scratch per lane) hide more of
+        // the load latency than two; with longer K loops the spilled words cost more than that buys (measured per shape).
+        static const int occ3 = [] { const char* e = std::getenv("POCKET_TTS_GEMM_OCC3"); return e ? std::atoi(e) : 1; }();
+        if (occ3 && a.K <= 1024) {
+            if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<false, true, false, false, 3>), grid, block, 0, s, a, gw);
+            else hipLaunchKernelGGL((gemm_lean_kernel<false, false, false, false, 3>), grid, block, 0, s, a, gw);
+        } else
         if (a.c_bf16) hipLaunchKernelGGL((gemm_lean_kernel<false, true, false>), grid, block, 0, s, a, gw);
         else hipLaunchKernelGGL((gemm_lean_kernel<false, false, false>), grid, block, 0, s, a, gw);
     }
