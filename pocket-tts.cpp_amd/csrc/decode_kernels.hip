@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <algorithm>
 #include <stdexcept>
 #include <type_traits>
@@ -411,6 +412,120 @@ std::vector<unsigned char> pack_q8_layout(const signed char* q, int N, int K) {
     return out;
 }
 
+
+// ---- rows-stationary product: a few hundred rows against thousands of columns at K = 512 ------------------------
+// (the adaLN vectors of a frame: 640 x 10240 x 512).  In skinny_gemm_kernel every workgroup of 64 columns stages its
+// rows again (3200 workgroups x 64 KB through LDS at that shape) and that staging, not the matrix work, is its time.
+// Here a wave keeps the two-term bf16 fragments of its 32 rows in registers for the whole launch (256 registers, read
+// straight from memory in fragment order, no LDS) and the weights stream past them: a workgroup is 4 waves = 128 rows
+// and walks its share of the 16-column tiles; each wave fetches a quarter of the next tiles' fragments three tiles
+// ahead (six were measured no faster: the weight stream is not what a tile waits for), the tile meets the four waves through a two-slot LDS buffer (one barrier per tile), 64 MFMAs per wave and
+// tile.  Workgroup L runs on XCD L % 8 and takes column partition (L % 8) + 8 k: an XCD's L2 sees an eighth of the
+// weights and every row.  Products are accumulated in skinny_gemm_kernel's order (k-steps ascending, low term
+// before high term), so the result is the same bit for bit.
+constexpr int kWideK = 512, kWideKS = kWideK / 32, kWideRows = 128, kWideAhead = 3;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk) {
+    __shared__ __attribute__((aligned(16))) u32x4 Wl[2][kWideKS * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int slab = j / pk, P = 8 * pk, part = xcd + 8 * (j % pk);
+    const int NT = a.N / 16;
+    const int t0 = (int)((long long)part * NT / P), n = (int)((long long)(part + 1) * NT / P) - t0;
+    const int m0 = slab * kWideRows + wave * 32;
+    const u32x4* wp = (const u32x4*)a.Wp + (long long)t0 * kWideKS * 64 + (4 * wave) * 64 + lane;
+
+    if (n <= 0) return;
+    // A staging set = this wave's quarter of a tile's fragments and the tile's bias element, requested three tiles ahead.
+    // Tiles past the partition's end re-read its last tile: every load is unconditional and the main loop below is
+    // straight-line code, so each wait counts exactly the requests issued after the one it needs (a conditional load or
+    // store anywhere in the loop makes every wait a full drain, stores included).
+    u32x4 st0[4], st1[4], st2[4];
+    float sb0, sb1, sb2;
+    auto issue = [&](u32x4 (&dst)[4], float& bias, int i) {
+        const int ii = i < n ? i : n - 1;
+        const u32x4* w = wp + (long long)ii * kWideKS * 64;
+        bias = a.bias[(t0 + ii) * 16 + r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = w[q * 64];
+    };
+    issue(st0, sb0, 0);
+    issue(st1, sb1, 1);
+    issue(st2, sb2, 2);
+
+    bf16x8 ah[2][kWideKS], al[2][kWideKS];
+    // the 32 loads of a 16-row tile are all requested before the first is converted (the pins keep the compiler from
+    // pairing each load with its conversion, which costs one memory round trip per pair)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const float* ap = a.A + (long long)(m0 + mt * 16 + r) * a.lda + 8 * g;
+        float4 v[2 * kWideKS];
+#pragma unroll
+        for (int ks = 0; ks < kWideKS; ++ks) { v[2 * ks] = *(const float4*)(ap + ks * 32); v[2 * ks + 1] = *(const float4*)(ap + ks * 32 + 4); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < kWideKS; ++ks) {
+            bf16x4 h0, l0, h1, l1;
+            split_bf16(v[2 * ks], h0, l0);
+            split_bf16(v[2 * ks + 1], h1, l1);
+            ah[mt][ks] = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            al[mt][ks] = bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    float* crow = a.C + (long long)(m0 + g * 4) * a.ldc + t0 * 16 + r;
+    auto step = [&](u32x4 (&cur)[4], float& bias, int i) {
+        u32x4* slot = Wl[i & 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) slot[(4 * wave + q) * 64 + lane] = cur[q];
+        const float bias_col = bias;
+        __syncthreads();
+        issue(cur, bias, i + kWideAhead);
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        // every fragment of the tile is requested from LDS before the first MFMA (one LDS latency per tile, not one per k-step)
+        u32x4 bw[kWideKS];
+#pragma unroll
+        for (int ks = 0; ks < kWideKS; ++ks) bw[ks] = slot[ks * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < kWideKS; ++ks) {
+            const bf16x8 b8 = __builtin_bit_cast(bf16x8, bw[ks]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt][ks], b8, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt][ks], b8, acc[mt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float* c = crow + i * 16;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[(long long)(mt * 16 + e) * a.ldc] = acc[mt][e] + bias_col;
+        }
+    };
+    int i = 0;
+    for (; i + kWideAhead <= n; i += kWideAhead) {
+        step(st0, sb0, i);
+        step(st1, sb1, i + 1);
+        step(st2, sb2, i + 2);
+    }
+    if (i < n) step(st0, sb0, i);          // n is the same for the whole workgroup: these barriers are uniform
+    if (i + 1 < n) step(st1, sb1, i + 1);
+}
+
+// Whether launch_skinny_gemm hands this product to wide_rows_kernel: bf16 weights, K = 512, plain C = acc + bias, whole
+// 128-row slabs (no row guards in the kernel), at least 256 rows and enough column tiles for every partition.  POCKET_TTS_WIDE_ROWS=0 keeps skinny_gemm_kernel.
+static bool wide_rows_eligible(const SkinnyArgs& a) {
+    const char* e = std::getenv("POCKET_TTS_WIDE_ROWS");   // read per launch (launches are captured once per graph): tests flip it
+    const bool on = !e || std::atoi(e) != 0;
+    return on && a.wtype == W_BF16 && a.K == kWideK && a.splits == 1 && !a.P && a.C && a.bias && a.act == ACT_NONE && !a.colscale && !a.R &&
+           !a.Aq && !a.Cq && a.M >= 256 && a.M % kWideRows == 0 && a.N / 16 >= 256;
+}
+
 void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return;
     const bool bf = a.wtype == W_BF16;
@@ -419,6 +534,12 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
     if (a.N % 16 || a.K % kstep || a.splits <= 0 || a.K % a.splits || (a.K / a.splits) % kstep || (!a.Aq && ((a.lda % 4) || ((uintptr_t)a.A & 15))))
         throw std::runtime_error("skinny gemm: shape not tileable (N % 16, K % k-step, K % splits, lda alignment)");
     if (!a.P && a.splits != 1) throw std::runtime_error("skinny gemm: split K needs a partial buffer");
+    if (wide_rows_eligible(a)) {
+        const int slabs = (a.M + kWideRows - 1) / kWideRows;
+        const int pk = std::max(1, std::min(a.N / 16 / 8 / 4, (256 + 4 * slabs) / (8 * slabs)));   // about one workgroup per CU, >= 4 tiles each
+        hipLaunchKernelGGL(wide_rows_kernel, dim3(8 * pk * slabs), dim3(256), 0, s, a, pk);
+        return;
+    }
     dim3 grid((a.N + 63) / 64, a.splits, (a.M + 63) / 64), block(256);
     // rows per workgroup: 64, 32 or 16.  Fewer rows = more workgroups streaming the same weights (served by the
     // XCD's L2 after the first: same-column workgroups differ by a multiple of 8 in linear id when grid.x * grid.y

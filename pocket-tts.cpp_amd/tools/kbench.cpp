@@ -307,6 +307,36 @@ int main(int argc, char** argv) {
         bench_skinny_q8p("q8p ff2 sp4", 64, 1024, 4096, 4, false);
         bench_skinny_q8p("q8p ff2 sp16", 64, 1024, 4096, 16, false);
     }
+    if (want("ada_dump")) {   // the adaLN product's result bytes into $KB_DUMP (compare POCKET_TTS_WIDE_ROWS=1 / 0 with cmp); KB_DUMP_M rows
+        const int M = std::getenv("KB_DUMP_M") ? std::atoi(std::getenv("KB_DUMP_M")) : 640, N = 10240, K = 512;
+        SkinnyArgs a;
+        a.A = (const float*)dalloc((size_t)M * K * 4); a.lda = K;
+        a.Wp = packed_weight(N, K, W_BF16); a.wtype = W_BF16;
+        a.M = M; a.N = N; a.K = K; a.splits = 1; a.mtiles = 2; a.kchunk = 128;
+        a.bias = (const float*)dalloc((size_t)N * 4);
+        a.C = (float*)dalloc((size_t)M * N * 4, 0); a.ldc = N;
+        launch_skinny_gemm(a, nullptr);
+        CK(hipDeviceSynchronize());
+        std::vector<float> h((size_t)M * N);
+        CK(hipMemcpy(h.data(), a.C, h.size() * 4, hipMemcpyDeviceToHost));
+        double sum = 0;
+        for (float v : h) sum += std::fabs(v);
+        std::printf("ada_dump M=%d: sum|C| = %.6f\n", M, sum);
+        if (const char* path = std::getenv("KB_DUMP")) {
+            FILE* f = std::fopen(path, "wb");
+            if (f) { std::fwrite(h.data(), 4, h.size(), f); std::fclose(f); }
+        }
+    }
+    if (want("ada")) {   // the adaLN product as the flow phase launches it (with its bias)
+        const int M = 640, N = 10240, K = 512;
+        SkinnyArgs a;
+        a.A = (const float*)dalloc((size_t)M * K * 4); a.lda = K;
+        a.Wp = packed_weight(N, K, W_BF16); a.wtype = W_BF16;
+        a.M = M; a.N = N; a.K = K; a.splits = 1; a.mtiles = 2; a.kchunk = 128;
+        a.bias = (const float*)dalloc((size_t)N * 4);
+        a.C = (float*)dalloc((size_t)M * N * 4, 0); a.ldc = N;
+        time_it("ada product", 300, [&](hipStream_t s) { launch_skinny_gemm(a, s); }, (double)N * K * 2 + (double)M * K * 4 + (double)M * N * 4, 2.0 * M * N * K);
+    }
     if (want("skinny_ada")) {
         for (int mt : {4, 2, 1})
             for (int kch : {128, 256}) {
