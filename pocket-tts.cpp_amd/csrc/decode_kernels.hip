@@ -416,25 +416,30 @@ std::vector<unsigned char> pack_q8_layout(const signed char* q, int N, int K) {
 // ---- rows-stationary product: a few hundred rows against thousands of columns at K = 512 ------------------------
 // (the adaLN vectors of a frame: 640 x 10240 x 512).  In skinny_gemm_kernel every workgroup of 64 columns stages its
 // rows again (3200 workgroups x 64 KB through LDS at that shape) and that staging, not the matrix work, is its time.
-// Here a wave keeps the two-term bf16 fragments of its 32 rows in registers for the whole launch (256 registers, read
-// straight from memory in fragment order, no LDS) and the weights stream past them: a workgroup is 4 waves = 128 rows
+// Here a wave keeps the two-term bf16 fragments of its 32 rows in registers for the whole launch (256 registers) and
+// the weights stream past them: a workgroup is 4 waves = 128 rows
 // and walks its share of the 16-column tiles; each wave fetches a quarter of the next tiles' fragments three tiles
 // ahead (six were measured no faster: the weight stream is not what a tile waits for), the tile meets the four waves through a two-slot LDS buffer (one barrier per tile), 64 MFMAs per wave and
 // tile.  Workgroup L runs on XCD L % 8 and takes column partition (L % 8) + 8 k: an XCD's L2 sees an eighth of the
 // weights and every row.  Products are accumulated in skinny_gemm_kernel's order (k-steps ascending, low term
 // before high term), so the result is the same bit for bit.
-constexpr int kWideK = 512, kWideKS = kWideK / 32, kWideRows = 128, kWideAhead = 3;
+constexpr int kWideK = 512, kWideKS = kWideK / 32, kWideAhead = 3, kWideLd = 64 + 8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-__global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk) {
+// MT: 16-row tiles per wave.  2: 32 rows per wave, one workgroup (128 rows) per CU.  1: 16 rows per wave in 128 fragment
+// registers, two workgroups (64 rows each) per CU, so that one's barrier and LDS phases run under the other's MFMAs.
+template <int MT>
+__global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void wide_rows_kernel(SkinnyArgs a, int pk) {
+    constexpr int kWideRows = 64 * MT;
     __shared__ __attribute__((aligned(16))) u32x4 Wl[2][kWideKS * 64];
+    __shared__ __attribute__((aligned(16))) __bf16 Astage[4][2][16 * kWideLd];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int slab = j / pk, P = 8 * pk, part = xcd + 8 * (j % pk);
     const int NT = a.N / 16;
     const int t0 = (int)((long long)part * NT / P), n = (int)((long long)(part + 1) * NT / P) - t0;
-    const int m0 = slab * kWideRows + wave * 32;
+    const int m0 = slab * kWideRows + wave * 16 * MT;
     const u32x4* wp = (const u32x4*)a.Wp + (long long)t0 * kWideKS * 64 + (4 * wave) * 64 + lane;
 
     if (n <= 0) return;
@@ -455,25 +460,48 @@ __global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk)
     issue(st1, sb1, 1);
     issue(st2, sb2, 2);
 
-    bf16x8 ah[2][kWideKS], al[2][kWideKS];
-    // the 32 loads of a 16-row tile are all requested before the first is converted (the pins keep the compiler from
-    // pairing each load with its conversion, which costs one memory round trip per pair)
+    bf16x8 ah[MT][kWideKS], al[MT][kWideKS];
+    // Row fragments.  Read in fragment order, a wave instruction would touch 64 different 128-byte lines for 16 bytes each
+    // (a lane per row); instead each wave reads its rows in row-major runs (16 lanes = 256 contiguous bytes), splits
+    // them into the two bf16 terms, and turns 16 rows x 64 k at a time into fragment order through a staging area of its
+    // own in LDS (a wave's LDS operations execute in order, so no workgroup barrier is involved).
+    {
+        __bf16* sh = Astage[wave][0];
+        __bf16* sl = Astage[wave][1];
+        const int lrow = lane >> 4, lk = (lane & 15) * 4;
+        // every load of the wave's rows is requested before the first conversion (MT x 32 float4 per lane)
+        float4 v[MT][kWideK / 64][4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const float* ap = a.A + (long long)(m0 + mt * 16 + r) * a.lda + 8 * g;
-        float4 v[2 * kWideKS];
+        for (int mt = 0; mt < MT; ++mt) {
+            const float* ap = a.A + (long long)(m0 + mt * 16 + lrow) * a.lda + lk;
 #pragma unroll
-        for (int ks = 0; ks < kWideKS; ++ks) { v[2 * ks] = *(const float4*)(ap + ks * 32); v[2 * ks + 1] = *(const float4*)(ap + ks * 32 + 4); }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int kc = 0; kc < kWideK / 64; ++kc)
 #pragma unroll
-        for (int ks = 0; ks < kWideKS; ++ks) {
-            bf16x4 h0, l0, h1, l1;
-            split_bf16(v[2 * ks], h0, l0);
-            split_bf16(v[2 * ks + 1], h1, l1);
-            ah[mt][ks] = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-            al[mt][ks] = bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                for (int i = 0; i < 4; ++i) v[mt][kc][i] = *(const float4*)(ap + (long long)(4 * i) * a.lda + kc * 64);
         }
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int kc = 0; kc < kWideK / 64; ++kc) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bf16x4 hi, lo;
+                    split_bf16(v[mt][kc][i], hi, lo);
+                    *(bf16x4*)(sh + (lrow + 4 * i) * kWideLd + lk) = hi;
+                    *(bf16x4*)(sl + (lrow + 4 * i) * kWideLd + lk) = lo;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    ah[mt][kc * 2 + j] = *(const bf16x8*)(sh + r * kWideLd + j * 32 + 8 * g);
+                    al[mt][kc * 2 + j] = *(const bf16x8*)(sl + r * kWideLd + j * 32 + 8 * g);
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
 
     float* crow = a.C + (long long)(m0 + g * 4) * a.ldc + t0 * 16 + r;
@@ -484,7 +512,9 @@ __global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk)
         const float bias_col = bias;
         __syncthreads();
         issue(cur, bias, i + kWideAhead);
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         // every fragment of the tile is requested from LDS before the first MFMA (one LDS latency per tile, not one per k-step)
         u32x4 bw[kWideKS];
 #pragma unroll
@@ -494,7 +524,7 @@ __global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk)
         for (int ks = 0; ks < kWideKS; ++ks) {
             const bf16x8 b8 = __builtin_bit_cast(bf16x8, bw[ks]);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt][ks], b8, acc[mt], 0, 0, 0);
                 acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt][ks], b8, acc[mt], 0, 0, 0);
             }
@@ -502,7 +532,7 @@ __global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk)
         __builtin_amdgcn_sched_barrier(0);
         float* c = crow + i * 16;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) c[(long long)(mt * 16 + e) * a.ldc] = acc[mt][e] + bias_col;
         }
@@ -518,12 +548,13 @@ __global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk)
 }
 
 // Whether launch_skinny_gemm hands this product to wide_rows_kernel: bf16 weights, K = 512, plain C = acc + bias, whole
-// 128-row slabs (no row guards in the kernel), at least 256 rows and enough column tiles for every partition.  POCKET_TTS_WIDE_ROWS=0 keeps skinny_gemm_kernel.
+// 64-row slabs (no row guards in the kernel), at least 256 rows and enough column tiles for every partition.
+// POCKET_TTS_WIDE_ROWS=0 keeps skinny_gemm_kernel.
 static bool wide_rows_eligible(const SkinnyArgs& a) {
     const char* e = std::getenv("POCKET_TTS_WIDE_ROWS");   // read per launch (launches are captured once per graph): tests flip it
     const bool on = !e || std::atoi(e) != 0;
     return on && a.wtype == W_BF16 && a.K == kWideK && a.splits == 1 && !a.P && a.C && a.bias && a.act == ACT_NONE && !a.colscale && !a.R &&
-           !a.Aq && !a.Cq && a.M >= 256 && a.M % kWideRows == 0 && a.N / 16 >= 256;
+           !a.Aq && !a.Cq && a.M >= 256 && a.M % 64 == 0 && a.N / 16 >= 256;
 }
 
 void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
@@ -535,9 +566,15 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
         throw std::runtime_error("skinny gemm: shape not tileable (N % 16, K % k-step, K % splits, lda alignment)");
     if (!a.P && a.splits != 1) throw std::runtime_error("skinny gemm: split K needs a partial buffer");
     if (wide_rows_eligible(a)) {
-        const int slabs = (a.M + kWideRows - 1) / kWideRows;
-        const int pk = std::max(1, std::min(a.N / 16 / 8 / 4, (256 + 4 * slabs) / (8 * slabs)));   // about one workgroup per CU, >= 4 tiles each
-        hipLaunchKernelGGL(wide_rows_kernel, dim3(8 * pk * slabs), dim3(256), 0, s, a, pk);
+        // 32 rows per wave and one workgroup per CU where the rows fill 128-row slabs (measured faster: 23 against 26 us at
+        // 640 x 10240), 16 rows per wave and two workgroups per CU otherwise; POCKET_TTS_WIDE_ROWS=1 forces the second form
+        const char* e = std::getenv("POCKET_TTS_WIDE_ROWS");
+        const int mt = (a.M % 128 == 0 && !(e && std::atoi(e) == 1)) ? 2 : 1;
+        const int slabs = a.M / (64 * mt), per_cu = mt == 1 ? 2 : 1;
+        // about per_cu workgroups per CU, at least 4 tiles each
+        const int pk = std::max(1, std::min(a.N / 16 / 8 / 4, (256 * per_cu + 4 * slabs) / (8 * slabs)));
+        if (mt == 2) hipLaunchKernelGGL(wide_rows_kernel<2>, dim3(8 * pk * slabs), dim3(256), 0, s, a, pk);
+        else hipLaunchKernelGGL(wide_rows_kernel<1>, dim3(8 * pk * slabs), dim3(256), 0, s, a, pk);
         return;
     }
     dim3 grid((a.N + 63) / 64, a.splits, (a.M + 63) / 64), block(256);

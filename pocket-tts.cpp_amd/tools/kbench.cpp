@@ -328,7 +328,7 @@ int main(int argc, char** argv) {
         }
     }
     if (want("ada")) {   // the adaLN product as the flow phase launches it (with its bias)
-        const int M = 640, N = 10240, K = 512;
+        const int M = std::getenv("KB_ADA_M") ? std::atoi(std::getenv("KB_ADA_M")) : 640, N = std::getenv("KB_ADA_N") ? std::atoi(std::getenv("KB_ADA_N")) : 10240, K = 512;
         SkinnyArgs a;
         a.A = (const float*)dalloc((size_t)M * K * 4); a.lda = K;
         a.Wp = packed_weight(N, K, W_BF16); a.wtype = W_BF16;

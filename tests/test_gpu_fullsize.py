@@ -261,12 +261,13 @@ def test_flow_head_persistent_form_matches_launch_chain(full):
 
 def test_adaln_product_rows_stationary_form_is_bit_equal(full):
     """The adaLN product of a frame (10 Euler steps x rows against 10240 columns, K = 512) runs on a kernel of its own
-    when the row count fills whole 128-row slabs (64 and 128 utterances: 640 / 1280 rows); it accumulates in the order of
-    the kernel it replaces, so the flow head's output must not change by a bit when POCKET_TTS_WIDE_ROWS=0 selects the
-    older kernel.  96 rows (960 = 7.5 slabs) takes the older kernel either way."""
+    when the row count fills whole 64-row slabs; it accumulates in the order of the kernel it replaces, so the flow head's
+    output must not change by a bit when POCKET_TTS_WIDE_ROWS=0 selects the older kernel.  64 and 128 utterances (640 /
+    1280 rows) take the form with 32 rows per wave, 96 (960 rows = 15 slabs of 64) the form with 16, 70 (700 rows) the
+    older kernel either way."""
     eng = full["lib"].Engine(full["path"], precision="bf16", temperature=0.0, lsd_steps=10, max_frames=F)
     rng = np.random.default_rng(23)
-    for rows in (64, 128, 96):
+    for rows in (64, 128, 96, 70):
         cond = rng.standard_normal((rows, full["spec"].d_model)).astype(np.float32)
         x0 = (rng.standard_normal((rows, full["spec"].latent_dim)) * 0.8).astype(np.float32)
         wide = eng.flow_euler(cond, x0)
