@@ -426,10 +426,12 @@ std::vector<unsigned char> pack_q8_layout(const signed char* q, int N, int K) {
 constexpr int kWideK = 512, kWideKS = kWideK / 32, kWideAhead = 3, kWideLd = 64 + 8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-// MT: 16-row tiles per wave.  2: 32 rows per wave, one workgroup (128 rows) per CU.  1: 16 rows per wave in 128 fragment
-// registers, two workgroups (64 rows each) per CU, so that one's barrier and LDS phases run under the other's MFMAs.
+// MT: 16-row tiles per wave.  2: 32 rows per wave, 128 rows per workgroup.  1: 16 rows per wave, for row counts that fill
+// 64-row slabs only.  One workgroup per CU either way: two of the second form per CU (256 registers, a few spilled) were
+// measured slower (25.5 against 23 us); two tiles per barrier were measured too (24 us, no gain).  Whatever the form,
+// the launch takes about 36 cycles per MFMA where 16 is the issue rate.
 template <int MT>
-__global__ __launch_bounds__(256, MT == 1 ? 2 : 1) void wide_rows_kernel(SkinnyArgs a, int pk) {
+__global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk) {
     constexpr int kWideRows = 64 * MT;
     __shared__ __attribute__((aligned(16))) u32x4 Wl[2][kWideKS * 64];
     __shared__ __attribute__((aligned(16))) __bf16 Astage[4][2][16 * kWideLd];
@@ -566,13 +568,12 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
         throw std::runtime_error("skinny gemm: shape not tileable (N % 16, K % k-step, K % splits, lda alignment)");
     if (!a.P && a.splits != 1) throw std::runtime_error("skinny gemm: split K needs a partial buffer");
     if (wide_rows_eligible(a)) {
-        // 32 rows per wave and one workgroup per CU where the rows fill 128-row slabs (measured faster: 23 against 26 us at
-        // 640 x 10240), 16 rows per wave and two workgroups per CU otherwise; POCKET_TTS_WIDE_ROWS=1 forces the second form
+        // 32 rows per wave where the rows fill 128-row slabs, 16 otherwise (POCKET_TTS_WIDE_ROWS=1 forces the second form)
         const char* e = std::getenv("POCKET_TTS_WIDE_ROWS");
         const int mt = (a.M % 128 == 0 && !(e && std::atoi(e) == 1)) ? 2 : 1;
-        const int slabs = a.M / (64 * mt), per_cu = mt == 1 ? 2 : 1;
-        // about per_cu workgroups per CU, at least 4 tiles each
-        const int pk = std::max(1, std::min(a.N / 16 / 8 / 4, (256 * per_cu + 4 * slabs) / (8 * slabs)));
+        const int slabs = a.M / (64 * mt);
+        // about one workgroup per CU, at least 4 tiles each
+        const int pk = std::max(1, std::min(a.N / 16 / 8 / 4, (256 + 4 * slabs) / (8 * slabs)));
         if (mt == 2) hipLaunchKernelGGL(wide_rows_kernel<2>, dim3(8 * pk * slabs), dim3(256), 0, s, a, pk);
         else hipLaunchKernelGGL(wide_rows_kernel<1>, dim3(8 * pk * slabs), dim3(256), 0, s, a, pk);
         return;
