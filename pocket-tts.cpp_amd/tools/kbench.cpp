@@ -136,6 +136,76 @@ static void bench_gemm(const char* name, int M, int N, int K, int split_a, int l
     time_it(name, 50, [&](hipStream_t s) { launch_gemm(g, s); }, (double)N * K * 2 + (double)M * lda * 4 + (double)M * N * 4, 2.0 * M * N * K);
 }
 
+
+// ---- MFMA issue rate with the operand pattern of wide_rows_kernel: 64 row fragments of 4 registers each held per wave
+// (256 registers, so about half of them live in AccVGPRs), 16 column fragments per "tile", 64 MFMAs per tile on two
+// accumulators.  LDSB = 1: the 16 column fragments are re-read from LDS for every tile, as in the kernel.
+typedef __attribute__((ext_vector_type(8))) __bf16 kb_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float kb_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned kb_u32x4;
+template <int LDSB>
+__global__ __launch_bounds__(256, 1) void mfma_rate_kernel(const kb_u32x4* src, float* out, int tiles) {
+    __shared__ __attribute__((aligned(16))) kb_u32x4 Wl[16 * 64];
+    const int lane = threadIdx.x & 63;
+    kb_bf16x8 ah[2][16], al[2][16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            ah[mt][ks] = __builtin_bit_cast(kb_bf16x8, src[((mt * 16 + ks) * 2 + 0) * 64 + lane]);
+            al[mt][ks] = __builtin_bit_cast(kb_bf16x8, src[((mt * 16 + ks) * 2 + 1) * 64 + lane]);
+        }
+    kb_u32x4 bw[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) { bw[ks] = src[(64 + ks) * 64 + lane]; Wl[ks * 64 + lane] = bw[ks]; }
+    __syncthreads();
+    kb_f32x4 acc[2] = {kb_f32x4{0.f, 0.f, 0.f, 0.f}, kb_f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int t = 0; t < tiles; ++t) {
+        if (LDSB) {
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) bw[ks] = Wl[ks * 64 + ((lane + t) & 63)];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const kb_bf16x8 b8 = __builtin_bit_cast(kb_bf16x8, bw[ks]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt][ks], b8, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt][ks], b8, acc[mt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = acc[0][0] + acc[0][1] + acc[0][2] + acc[0][3] + acc[1][0] + acc[1][1] + acc[1][2] + acc[1][3];
+}
+
+static void bench_mfma_rate() {
+    const int tiles = 2000, wgs = 256;
+    void* src = dalloc((size_t)(64 + 16) * 64 * 16 + 4096);
+    float* out = (float*)dalloc((size_t)wgs * 256 * 4, 0);
+    for (int ldsb = 0; ldsb < 2; ++ldsb)
+        for (int n : {wgs, 64}) {
+            hipEvent_t a, b;
+            CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+            auto run = [&] {
+                if (ldsb) hipLaunchKernelGGL(mfma_rate_kernel<1>, dim3(n), dim3(256), 0, nullptr, (const kb_u32x4*)src, out, tiles);
+                else hipLaunchKernelGGL(mfma_rate_kernel<0>, dim3(n), dim3(256), 0, nullptr, (const kb_u32x4*)src, out, tiles);
+            };
+            run();
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(a, nullptr));
+            run();
+            CK(hipEventRecord(b, nullptr));
+            CK(hipEventSynchronize(b));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, a, b));
+            const double ns_per_mfma = ms * 1e6 / ((double)tiles * 64);
+            std::printf("mfma_rate lds=%d workgroups=%3d: %.2f ns per MFMA and wave (%.1f cycles at 2.4 GHz), %.0f TFLOP/s\n", ldsb, n, ns_per_mfma,
+                        ns_per_mfma * 2.4, (double)n * 4 * tiles * 64 * 16384.0 / (ms * 1e-3) * 1e-12);
+        }
+}
+
 static void bench_flow(int B) {
     const char* wenv = std::getenv("KB_FLOW_WTYPE");
     const int W_T = wenv && !std::strcmp(wenv, "f32") ? W_F32 : W_BF16;
@@ -307,6 +377,7 @@ int main(int argc, char** argv) {
         bench_skinny_q8p("q8p ff2 sp4", 64, 1024, 4096, 4, false);
         bench_skinny_q8p("q8p ff2 sp16", 64, 1024, 4096, 16, false);
     }
+    if (want("mfma_rate")) bench_mfma_rate();
     if (want("ada_dump")) {   // the adaLN product's result bytes into $KB_DUMP (compare POCKET_TTS_WIDE_ROWS=1 / 0 with cmp); KB_DUMP_M rows
         const int M = std::getenv("KB_DUMP_M") ? std::atoi(std::getenv("KB_DUMP_M")) : 640, N = 10240, K = 512;
         SkinnyArgs a;
