@@ -430,7 +430,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // 64-row slabs only.  One workgroup per CU either way: two of the second form per CU (256 registers, a few spilled) were
 // measured slower (25.5 against 23 us); two tiles per barrier were measured too (24 us, no gain).  Whatever the form,
 // the launch takes about 36 cycles per MFMA where 16 is the issue rate.
-template <int MT>
+// FRAG: the rows arrive as two-term bf16 fragments (SkinnyArgs::a_frag): one 16-byte load per fragment, no conversion,
+// no staging.
+template <int MT, bool FRAG>
 __global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk) {
     constexpr int kWideRows = 64 * MT;
     __shared__ __attribute__((aligned(16))) u32x4 Wl[2][kWideKS * 64];
@@ -467,6 +469,17 @@ __global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk)
     // (a lane per row); instead each wave reads its rows in row-major runs (16 lanes = 256 contiguous bytes), splits
     // them into the two bf16 terms, and turns 16 rows x 64 k at a time into fragment order through a staging area of its
     // own in LDS (a wave's LDS operations execute in order, so no workgroup barrier is involved).
+    if constexpr (FRAG) {
+        const u32x4* af = (const u32x4*)a.A + lane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < kWideKS; ++ks) {
+                const long long unit = ((long long)(m0 / 16 + mt) * kWideKS + ks) * 2;
+                ah[mt][ks] = __builtin_bit_cast(bf16x8, af[unit * 64]);
+                al[mt][ks] = __builtin_bit_cast(bf16x8, af[(unit + 1) * 64]);
+            }
+    } else
     {
         __bf16* sh = Astage[wave][0];
         __bf16* sl = Astage[wave][1];
@@ -552,7 +565,7 @@ __global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk)
 // Whether launch_skinny_gemm hands this product to wide_rows_kernel: bf16 weights, K = 512, plain C = acc + bias, whole
 // 64-row slabs (no row guards in the kernel), at least 256 rows and enough column tiles for every partition.
 // POCKET_TTS_WIDE_ROWS=0 keeps skinny_gemm_kernel.
-static bool wide_rows_eligible(const SkinnyArgs& a) {
+bool skinny_wide_rows_applies(const SkinnyArgs& a) {
     const char* e = std::getenv("POCKET_TTS_WIDE_ROWS");   // read per launch (launches are captured once per graph): tests flip it
     const bool on = !e || std::atoi(e) != 0;
     return on && a.wtype == W_BF16 && a.K == kWideK && a.splits == 1 && !a.P && a.C && a.bias && a.act == ACT_NONE && !a.colscale && !a.R &&
@@ -567,15 +580,19 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
     if (a.N % 16 || a.K % kstep || a.splits <= 0 || a.K % a.splits || (a.K / a.splits) % kstep || (!a.Aq && ((a.lda % 4) || ((uintptr_t)a.A & 15))))
         throw std::runtime_error("skinny gemm: shape not tileable (N % 16, K % k-step, K % splits, lda alignment)");
     if (!a.P && a.splits != 1) throw std::runtime_error("skinny gemm: split K needs a partial buffer");
-    if (wide_rows_eligible(a)) {
+    if (a.a_frag && !skinny_wide_rows_applies(a)) throw std::runtime_error("skinny gemm: fragment-order rows are read by the rows-stationary kernel only");
+    if (skinny_wide_rows_applies(a)) {
         // 32 rows per wave where the rows fill 128-row slabs, 16 otherwise (POCKET_TTS_WIDE_ROWS=1 forces the second form)
         const char* e = std::getenv("POCKET_TTS_WIDE_ROWS");
         const int mt = (a.M % 128 == 0 && !(e && std::atoi(e) == 1)) ? 2 : 1;
         const int slabs = a.M / (64 * mt);
         // about one workgroup per CU, at least 4 tiles each
         const int pk = std::max(1, std::min(a.N / 16 / 8 / 4, (256 + 4 * slabs) / (8 * slabs)));
-        if (mt == 2) hipLaunchKernelGGL(wide_rows_kernel<2>, dim3(8 * pk * slabs), dim3(256), 0, s, a, pk);
-        else hipLaunchKernelGGL(wide_rows_kernel<1>, dim3(8 * pk * slabs), dim3(256), 0, s, a, pk);
+        const dim3 wgrid(8 * pk * slabs);
+        if (mt == 2 && a.a_frag) hipLaunchKernelGGL((wide_rows_kernel<2, true>), wgrid, dim3(256), 0, s, a, pk);
+        else if (mt == 2) hipLaunchKernelGGL((wide_rows_kernel<2, false>), wgrid, dim3(256), 0, s, a, pk);
+        else if (a.a_frag) hipLaunchKernelGGL((wide_rows_kernel<1, true>), wgrid, dim3(256), 0, s, a, pk);
+        else hipLaunchKernelGGL((wide_rows_kernel<1, false>), wgrid, dim3(256), 0, s, a, pk);
         return;
     }
     dim3 grid((a.N + 63) / 64, a.splits, (a.M + 63) / 64), block(256);

@@ -1159,13 +1159,20 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
     probe.block_wtype = model_->flow_block_wtype; probe.ring_split = model_->flow_ring_split; probe.ring_ctl = fs.ctl; probe.ring_wg_budget = 224 / std::max(lanes_, 1);
     const bool ring = owns_ring_ && fs.ctl && flow_ring_supported(probe);
     const int cw = static_cast<int>(flow_ring_counter_word());
-    launch_flow_mod_input(flow_te_.f(), fs.cemb, cs, hd_.flow_cond_b, fs.ymod, N, B, C, st, frame ? &pub : nullptr, ring ? fs.ctl + cw : nullptr,
-                          ring ? static_cast<int>(flow_ring_ctl_bytes(B, s.flow_blocks) / 4) - cw : 0);
+    // the adaLN product: where its rows-stationary kernel applies (640 x 10240 x 512 at 64 rows), the kernel in front of it
+    // leaves the rows as two-term bf16 fragments in the same buffer and the product loads them as they are
+    // (POCKET_TTS_ADA_F32_ROWS=1: f32 rows, converted and reordered by the product)
+    SkinnyArgs m;
     if (model_->ada_packed) {
-        SkinnyArgs m;
         m.A = fs.ymod; m.lda = C; m.Wp = model_->ada_packed; m.wtype = wt; m.M = N * B; m.N = model_->mod_width; m.K = C;
         m.bias = model_->ada_all_b; m.C = fs.mods; m.ldc = model_->mod_width;
         if (m.M > 128) { m.mtiles = 2; m.kchunk = 128; }   // measured at 640 x 10240 x 512: 32 us (64-row groups 39 us, tiled GEMM 66 us)
+        const char* f32_rows = std::getenv("POCKET_TTS_ADA_F32_ROWS");
+        if (skinny_wide_rows_applies(m) && !(f32_rows && std::atoi(f32_rows))) m.a_frag = 1;
+    }
+    launch_flow_mod_input(flow_te_.f(), fs.cemb, cs, hd_.flow_cond_b, fs.ymod, N, B, C, st, frame ? &pub : nullptr, ring ? fs.ctl + cw : nullptr,
+                          ring ? static_cast<int>(flow_ring_ctl_bytes(B, s.flow_blocks) / 4) - cw : 0, m.a_frag);
+    if (model_->ada_packed) {
         launch_skinny_gemm(m, st);
     } else {
         GemmArgs m;

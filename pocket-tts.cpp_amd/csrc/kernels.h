@@ -252,6 +252,7 @@ struct SkinnyArgs {
     // C form only (f32 / bf16 weights): C = act(acc + bias) * colscale + R
     const float* colscale = nullptr; const float* R = nullptr; int ldr = 0;
     const float* wscale = nullptr;   // W_I8: per-output-column weight scale
+    int a_frag = 0;                  // A holds two-term bf16 fragments (launch_flow_mod_input's frag form); only where skinny_wide_rows_applies()
     int mtiles = 0;                  // 16-row tiles per workgroup: 1, 2 or 4 (0 = 4)
     int kchunk = 0;                  // K elements staged per step: 128, 256 or 512 (bf16, mtiles <= 2); 0 = 128
     // W_I8 only, activations quantised by the kernel that produced them (per row and block of 64 k: q = rint(a * 127 / max|a|),
@@ -261,6 +262,8 @@ struct SkinnyArgs {
     signed char* Cq = nullptr; float* Cd = nullptr;
 };
 void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s);
+// Whether launch_skinny_gemm runs this product on the rows-stationary kernel (which alone understands a_frag).
+bool skinny_wide_rows_applies(const SkinnyArgs& a);
 
 // Per row m: X[m] += colscale * (sum_s P[s][m] + pbias)  (skipped when P is null), then
 // y = LayerNorm(X[m]; g, b) -> H, optional second copy H32, optional dot_out[m] = y . dot_w + dot_b,
@@ -304,7 +307,10 @@ struct FramePublish {
     int stride = 0;   // > 0: floats per step row of h_eos_all (default: B)
 };
 // zero / zero_words (optional): words the launch also sets to zero (the control words of a later kernel of the same frame)
+// frag: Y is written as the two bf16 terms of every value in MFMA fragment order instead of f32 rows (the same bytes in
+// all): 16-byte unit ((row / 16 * (C / 32) + k / 32) * 2 + term) * 64 + (k % 32 / 8) * 16 + row % 16 holds k % 8 = 0..7 of
+// row steps * B + b; needs C % 32 == 0 and steps * B % 16 == 0.  SkinnyArgs::a_frag reads it.
 void launch_flow_mod_input(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C, hipStream_t s,
-                           const FramePublish* pub = nullptr, unsigned* zero = nullptr, int zero_words = 0);
+                           const FramePublish* pub = nullptr, unsigned* zero = nullptr, int zero_words = 0, int frag = 0);
 
 }  // namespace ptts

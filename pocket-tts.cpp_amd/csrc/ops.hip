@@ -491,6 +491,10 @@ void launch_shift_history(float* buf, long long bs, int T, int H, int C, int B, 
 // A frame of the autoregressive loop is replayed as one hipGraph, so nothing in it may depend on a host-side frame
 // index: the index lives in device memory.  Block 0 of this launch also hands the EOS logits of the current frame to
 // the host through mapped pinned memory, raises the host-visible flag and advances the index.
+// FRAG: the value leaves as its two bf16 terms, hi = bf16(v) and lo = bf16(v - hi), in MFMA fragment order (see
+// launch_flow_mod_input's declaration): the product that consumes the rows loads each fragment with one 16-byte load
+// and neither converts nor reorders.  Eight consecutive threads fill one 16-byte unit of each term.
+template <bool FRAG>
 __global__ void flow_mod_input_kernel(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C,
                                       FramePublish pub, unsigned* zero, int zero_words) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -503,7 +507,16 @@ __global__ void flow_mod_input_kernel(const float* te, const float* cemb, int sp
         for (int s = 1; s < splits; ++s) e += cemb[((long long)s * B + b) * C + c];
         if (bias) e += bias[c];
         float v = te[(long long)j * C + c] + e;
-        Y[i] = v / (1.0f + expf(-v));
+        v = v / (1.0f + expf(-v));
+        if constexpr (FRAG) {
+            const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+            const long long unit = ((jb / 16) * (C / 32) + c / 32) * 2;
+            const long long at = (unit * 64 + (c % 32 / 8) * 16 + (int)(jb % 16)) * 8 + c % 8;
+            ((__bf16*)Y)[at] = hi;
+            ((__bf16*)Y)[at + 64 * 8] = lo;
+        } else {
+            Y[i] = v;
+        }
     }
     if (pub.step && blockIdx.x == 0) {   // frame bookkeeping: see FramePublish
         const int st = *pub.step;
@@ -518,11 +531,16 @@ __global__ void flow_mod_input_kernel(const float* te, const float* cemb, int sp
     }
 }
 void launch_flow_mod_input(const float* te, const float* cemb, int splits, const float* bias, float* Y, int steps, int B, int C, hipStream_t s,
-                           const FramePublish* pub, unsigned* zero, int zero_words) {
+                           const FramePublish* pub, unsigned* zero, int zero_words, int frag) {
     long long n = (long long)steps * B * C;
     if (n <= 0) return;
     if (zero_words % 4 || zero_words / 4 > n) throw std::runtime_error("flow_mod_input: cannot zero that many control words");
-    hipLaunchKernelGGL(flow_mod_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, te, cemb, splits, bias, Y, steps, B, C,
+    if (frag && (C % 32 || ((long long)steps * B) % 16)) throw std::runtime_error("flow_mod_input: fragment order needs C % 32 == 0 and rows % 16 == 0");
+    if (frag)
+        hipLaunchKernelGGL(flow_mod_input_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, te, cemb, splits, bias, Y, steps, B, C,
+                           pub ? *pub : FramePublish(), zero, zero ? zero_words : 0);
+    else
+    hipLaunchKernelGGL(flow_mod_input_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, te, cemb, splits, bias, Y, steps, B, C,
                        pub ? *pub : FramePublish(), zero, zero ? zero_words : 0);
 }
 

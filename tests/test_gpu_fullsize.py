@@ -277,6 +277,12 @@ def test_adaln_product_rows_stationary_form_is_bit_equal(full):
         finally:
             os.environ.pop("POCKET_TTS_WIDE_ROWS", None)
         np.testing.assert_array_equal(wide, plain)
+        os.environ["POCKET_TTS_ADA_F32_ROWS"] = "1"      # the same kernel fed f32 rows instead of ready bf16 fragments
+        try:
+            f32_rows = eng.flow_euler(cond, x0)
+        finally:
+            os.environ.pop("POCKET_TTS_ADA_F32_ROWS", None)
+        np.testing.assert_array_equal(wide, f32_rows)
         want = full["oq"].flow_euler(cond[rows - 1], x0[rows - 1], 10)
         assert float(np.abs(wide[rows - 1] - want).max()) <= 2e-2
     eng.close()
