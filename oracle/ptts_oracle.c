@@ -300,6 +300,20 @@ static KvState *kv_new(int layers, int d, int heads, int cap, int context) {
 }
 static void kv_free(KvState *st) { if (st) { free(st->k); free(st->v); free(st); } }
 
+/* Attribution knob (tools/bf16_attribution.py): with the flag set, the LM's K and V rows are rounded to bfloat16
+ * (nearest even) as they enter the cache, which is what the bf16 and int8 engines store.  Off by default. */
+static int g_lm_kv_bf16 = 0;
+void ptts_oracle_set_lm_kv_bf16(int on) { g_lm_kv_bf16 = on; }
+static inline float bf16_round_f(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return x;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
 /* One pre-norm transformer stack over R new rows X[R][d] (in place).
  * prefix selects "lm" or "dec"/"enc" tensors; layer scale vectors are optional (Mimi only). */
 static void transformer_rows(const Oracle *o, const char *prefix, KvState *st, float *X, int R,
@@ -325,6 +339,7 @@ static void transformer_rows(const Oracle *o, const char *prefix, KvState *st, f
             long p = st->pos + r;
             float *q = qkv + (size_t)r * 3 * d, *k = q + d, *v = q + 2 * d;
             for (int hh = 0; hh < H; ++hh) { rope(q + hh * dh, dh, p, max_period); rope(k + hh * dh, dh, p, max_period); }
+            if (g_lm_kv_bf16 && !has_ls) for (int e = 0; e < d; ++e) { k[e] = bf16_round_f(k[e]); v[e] = bf16_round_f(v[e]); }
             memcpy(kc + (size_t)(p % st->cap) * d, k, (size_t)d * sizeof(float));
             memcpy(vc + (size_t)(p % st->cap) * d, v, (size_t)d * sizeof(float));
         }

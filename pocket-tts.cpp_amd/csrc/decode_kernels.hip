@@ -59,9 +59,12 @@ __device__ __forceinline__ float act_dev(float v, int act) {
     }
 }
 
-template <typename CT, int MT, int KCH>
+// W2 (bf16 weights only): the matrix comes as two bf16 planes, W = Wp + Wp2 with Wp2 = bf16(W - Wp), and every fragment takes
+// a third MFMA (hi_a * lo_w): the product then carries both operands to ~16 mantissa bits.
+template <typename CT, int MT, int KCH, bool W2 = false>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     using T = SkinnyTraits<CT>;
+    static_assert(!W2 || !std::is_same<CT, float>::value, "skinny gemm: a second weight plane exists for bf16 matrices only");
     constexpr int ROWS = 16 * MT;           // rows per workgroup
     constexpr bool kBf16 = !std::is_same<CT, float>::value;
     constexpr int KSTEP = T::kstep, LDA = KCH + T::pad;
@@ -80,9 +83,11 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
     const int nchunks = (Kc + KCH - 1) / KCH;
     const int KS_total = a.K / KSTEP;
     const uint4* wbase = (const uint4*)a.Wp + (long long)nt * KS_total * 64 + lane;
+    const uint4* wbase2 = (const uint4*)(W2 ? a.Wp2 : a.Wp) + (long long)nt * KS_total * 64 + lane;
 
     float4 areg[APT];
     uint4 bnext[NKS], bcur[NKS];
+    uint4 bnext2[W2 ? NKS : 1], bcur2[W2 ? NKS : 1];
     auto load_chunk = [&](int c) {
         const int kc0 = c * KCH;  // offset inside the slice
 #pragma unroll
@@ -96,6 +101,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
         for (int i = 0; i < NKS; ++i) {
             const int k = kc0 + i * KSTEP;
             bnext[i] = (tile_live && k < Kc) ? wbase[(long long)((k_begin + k) / KSTEP) * 64] : make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (W2) bnext2[i] = (tile_live && k < Kc) ? wbase2[(long long)((k_begin + k) / KSTEP) * 64] : make_uint4(0u, 0u, 0u, 0u);
         }
     };
 
@@ -125,6 +131,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < NKS; ++i) bcur[i] = bnext[i];
+        if constexpr (W2) {
+#pragma unroll
+            for (int i = 0; i < NKS; ++i) bcur2[i] = bnext2[i];
+        }
         __syncthreads();
         if (c + 1 < nchunks) load_chunk(c + 1);
 #pragma unroll
@@ -144,6 +154,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs a) {
                 for (int mt = 0; mt < MT; ++mt) {
                     const bf16x8 lo8 = *(const bf16x8*)(buf_lo + (mt * 16 + r) * LDA + ks * 32 + 8 * g);
                     const bf16x8 hi8 = *(const bf16x8*)(buf + (mt * 16 + r) * LDA + ks * 32 + 8 * g);
+                    if constexpr (W2) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi8, __builtin_bit_cast(bf16x8, bcur2[ks]), acc[mt], 0, 0, 0);
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo8, b8, acc[mt], 0, 0, 0);
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi8, b8, acc[mt], 0, 0, 0);
                 }
@@ -432,11 +443,18 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // the launch takes about 36 cycles per MFMA where 16 is the issue rate.
 // FRAG: the rows arrive as two-term bf16 fragments (SkinnyArgs::a_frag): one 16-byte load per fragment, no conversion,
 // no staging.
-template <int MT, bool FRAG>
+// W2: the matrix comes as two bf16 planes (SkinnyArgs::Wp2); a tile then takes 96 MFMAs per wave instead of 64 and both
+// planes travel through LDS (the tile's fragments are read from LDS in two halves of 8 k-steps, which keeps the kernel
+// inside 512 registers).
+template <int MT, bool FRAG, bool W2>
 __global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk) {
     constexpr int kWideRows = 64 * MT;
-    __shared__ __attribute__((aligned(16))) u32x4 Wl[2][kWideKS * 64];
-    __shared__ __attribute__((aligned(16))) __bf16 Astage[4][2][16 * kWideLd];
+    constexpr int NPL = W2 ? 2 : 1;                          // weight planes
+    constexpr int kSlot = kWideKS * 64;                      // 16-byte units of one tile of one plane
+    // [plane][slot][k-step][lane]; the per-wave row staging areas of the prologue ([wave][term][16 * kWideLd] bf16) lie over
+    // the same bytes and are done with before the first tile is written (one barrier)
+    __shared__ __attribute__((aligned(16))) u32x4 Wl[NPL * 2 * kSlot];
+    static_assert(sizeof(u32x4) * 2 * kSlot >= 4 * 2 * 16 * kWideLd * sizeof(__bf16), "wide rows: the staging areas must fit under the tile slots");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -445,20 +463,26 @@ __global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk)
     const int t0 = (int)((long long)part * NT / P), n = (int)((long long)(part + 1) * NT / P) - t0;
     const int m0 = slab * kWideRows + wave * 16 * MT;
     const u32x4* wp = (const u32x4*)a.Wp + (long long)t0 * kWideKS * 64 + (4 * wave) * 64 + lane;
+    const u32x4* wp2 = (const u32x4*)(W2 ? a.Wp2 : a.Wp) + (long long)t0 * kWideKS * 64 + (4 * wave) * 64 + lane;
 
     if (n <= 0) return;
     // A staging set = this wave's quarter of a tile's fragments and the tile's bias element, requested three tiles ahead.
     // Tiles past the partition's end re-read its last tile: every load is unconditional and the main loop below is
     // straight-line code, so each wait counts exactly the requests issued after the one it needs (a conditional load or
     // store anywhere in the loop makes every wait a full drain, stores included).
-    u32x4 st0[4], st1[4], st2[4];
+    u32x4 st0[4 * NPL], st1[4 * NPL], st2[4 * NPL];
     float sb0, sb1, sb2;
-    auto issue = [&](u32x4 (&dst)[4], float& bias, int i) {
+    auto issue = [&](u32x4 (&dst)[4 * NPL], float& bias, int i) {
         const int ii = i < n ? i : n - 1;
         const u32x4* w = wp + (long long)ii * kWideKS * 64;
         bias = a.bias[(t0 + ii) * 16 + r];
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q] = w[q * 64];
+        if constexpr (W2) {
+            const u32x4* w2 = wp2 + (long long)ii * kWideKS * 64;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[4 + q] = w2[q * 64];
+        }
     };
     issue(st0, sb0, 0);
     issue(st1, sb1, 1);
@@ -481,8 +505,8 @@ __global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk)
             }
     } else
     {
-        __bf16* sh = Astage[wave][0];
-        __bf16* sl = Astage[wave][1];
+        __bf16* sh = (__bf16*)Wl + (wave * 2) * 16 * kWideLd;
+        __bf16* sl = sh + 16 * kWideLd;
         const int lrow = lane >> 4, lk = (lane & 15) * 4;
         // every load of the wave's rows is requested before the first conversion (MT x 32 float4 per lane)
         float4 v[MT][kWideK / 64][4];
@@ -517,34 +541,62 @@ __global__ __launch_bounds__(256, 1) void wide_rows_kernel(SkinnyArgs a, int pk)
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        __syncthreads();   // the staging areas lie under the tile slots
     }
 
     float* crow = a.C + (long long)(m0 + g * 4) * a.ldc + t0 * 16 + r;
-    auto step = [&](u32x4 (&cur)[4], float& bias, int i) {
-        u32x4* slot = Wl[i & 1];
+    auto step = [&](u32x4 (&cur)[4 * NPL], float& bias, int i) {
+        u32x4* slot = Wl + (i & 1) * kSlot;
+        u32x4* slot2 = Wl + (2 + (i & 1)) * kSlot;
 #pragma unroll
         for (int q = 0; q < 4; ++q) slot[(4 * wave + q) * 64 + lane] = cur[q];
+        if constexpr (W2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) slot2[(4 * wave + q) * 64 + lane] = cur[4 + q];
+        }
         const float bias_col = bias;
         __syncthreads();
         issue(cur, bias, i + kWideAhead);
         f32x4 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // every fragment of the tile is requested from LDS before the first MFMA (one LDS latency per tile, not one per k-step)
-        u32x4 bw[kWideKS];
+        if constexpr (W2) {
 #pragma unroll
-        for (int ks = 0; ks < kWideKS; ++ks) bw[ks] = slot[ks * 64 + lane];
-        __builtin_amdgcn_sched_barrier(0);
+            for (int h = 0; h < 2; ++h) {
+                constexpr int HK = kWideKS / 2;
+                u32x4 bw[HK], bw2[HK];
 #pragma unroll
-        for (int ks = 0; ks < kWideKS; ++ks) {
-            const bf16x8 b8 = __builtin_bit_cast(bf16x8, bw[ks]);
+                for (int ks = 0; ks < HK; ++ks) { bw[ks] = slot[(h * HK + ks) * 64 + lane]; bw2[ks] = slot2[(h * HK + ks) * 64 + lane]; }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt][ks], b8, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt][ks], b8, acc[mt], 0, 0, 0);
+                for (int ks = 0; ks < HK; ++ks) {
+                    const bf16x8 b8 = __builtin_bit_cast(bf16x8, bw[ks]), b8l = __builtin_bit_cast(bf16x8, bw2[ks]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt][h * HK + ks], b8l, acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt][h * HK + ks], b8, acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt][h * HK + ks], b8, acc[mt], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
+            // every fragment of the tile is requested from LDS before the first MFMA (one LDS latency per tile, not one per k-step)
+            u32x4 bw[kWideKS];
+#pragma unroll
+            for (int ks = 0; ks < kWideKS; ++ks) bw[ks] = slot[ks * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < kWideKS; ++ks) {
+                const bf16x8 b8 = __builtin_bit_cast(bf16x8, bw[ks]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt][ks], b8, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt][ks], b8, acc[mt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         float* c = crow + i * 16;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -589,10 +641,16 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
         // about one workgroup per CU, at least 4 tiles each
         const int pk = std::max(1, std::min(a.N / 16 / 8 / 4, (256 + 4 * slabs) / (8 * slabs)));
         const dim3 wgrid(8 * pk * slabs);
-        if (mt == 2 && a.a_frag) hipLaunchKernelGGL((wide_rows_kernel<2, true>), wgrid, dim3(256), 0, s, a, pk);
-        else if (mt == 2) hipLaunchKernelGGL((wide_rows_kernel<2, false>), wgrid, dim3(256), 0, s, a, pk);
-        else if (a.a_frag) hipLaunchKernelGGL((wide_rows_kernel<1, true>), wgrid, dim3(256), 0, s, a, pk);
-        else hipLaunchKernelGGL((wide_rows_kernel<1, false>), wgrid, dim3(256), 0, s, a, pk);
+        if (a.Wp2) {
+            if (mt == 2 && a.a_frag) hipLaunchKernelGGL((wide_rows_kernel<2, true, true>), wgrid, dim3(256), 0, s, a, pk);
+            else if (mt == 2) hipLaunchKernelGGL((wide_rows_kernel<2, false, true>), wgrid, dim3(256), 0, s, a, pk);
+            else if (a.a_frag) hipLaunchKernelGGL((wide_rows_kernel<1, true, true>), wgrid, dim3(256), 0, s, a, pk);
+            else hipLaunchKernelGGL((wide_rows_kernel<1, false, true>), wgrid, dim3(256), 0, s, a, pk);
+        }
+        else if (mt == 2 && a.a_frag) hipLaunchKernelGGL((wide_rows_kernel<2, true, false>), wgrid, dim3(256), 0, s, a, pk);
+        else if (mt == 2) hipLaunchKernelGGL((wide_rows_kernel<2, false, false>), wgrid, dim3(256), 0, s, a, pk);
+        else if (a.a_frag) hipLaunchKernelGGL((wide_rows_kernel<1, true, false>), wgrid, dim3(256), 0, s, a, pk);
+        else hipLaunchKernelGGL((wide_rows_kernel<1, false, false>), wgrid, dim3(256), 0, s, a, pk);
         return;
     }
     dim3 grid((a.N + 63) / 64, a.splits, (a.M + 63) / 64), block(256);
@@ -630,7 +688,15 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
     int kch = a.kchunk;
     if (kch != 128 && kch != 256 && kch != 512) kch = (mt == 1 && Kc >= 1024) ? 512 : (mt <= 2 && Kc >= 256) ? 256 : 128;
     if (Kc % kch) kch = 128;
-    if (bf) {
+    if (a.Wp2 && !bf) throw std::runtime_error("skinny gemm: a second weight plane goes with bf16 weights");
+    if (bf && a.Wp2) {   // two-term matrix: half the K chunk of the one-term form at most (twice the fragment registers)
+        if (kch == 512) kch = 256;
+        if (mt == 1 && kch == 256) hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 1, 256, true>), grid, block, 0, s, a);
+        else if (mt == 1) hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 1, 128, true>), grid, block, 0, s, a);
+        else if (mt == 2 && kch == 256) hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 2, 256, true>), grid, block, 0, s, a);
+        else if (mt == 2) hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 2, 128, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 4, 128, true>), grid, block, 0, s, a);
+    } else if (bf) {
         if (mt == 1 && kch == 512) hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 1, 512>), grid, block, 0, s, a);
         else if (mt == 1 && kch == 256) hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 1, 256>), grid, block, 0, s, a);
         else if (mt == 1) hipLaunchKernelGGL((skinny_gemm_kernel<__bf16, 1, 128>), grid, block, 0, s, a);

@@ -34,7 +34,54 @@ bool is_gemm_weight(const std::string& name) {
 
 size_t align256(size_t n) { return (n + 255) & ~static_cast<size_t>(255); }
 
+// v -> bf16(v) as a float, round to nearest even
+float bf16_part(float v) {
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    if ((u & 0x7f800000u) != 0x7f800000u) u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    std::memcpy(&v, &u, 4);
+    return v;
+}
+
 }  // namespace
+
+// Matrix families the reduced-precision engines keep as TWO bf16 terms, W = bf16(W) + bf16(W - bf16(W)), i.e. to ~16
+// mantissa bits (a third MFMA per fragment), instead of one.  Stored once in bf16, a matrix carries a relative error of
+// 2^-9 per element.  Measured on the float32 model with one family rounded at a time (tools/bf16_attribution.py) no family
+// owns the bf16 engine's distance from float32: eleven families contribute 3e-3 .. 1.4e-2 each to the per-frame latent
+// and add up in quadrature.  The default set is the one that buys the most per microsecond of frame time
+// (tools/bf16_attribution_gpu.py, bench A/B): the small projections at both ends of the LM step and of every Euler
+// step, and the conditioning and adaLN products of the flow phase.  The LM's FFN-2 is the next candidate (its skinny
+// product nearly doubles in time) and, like the LM's QKV and output projections, can be switched on:
+// POCKET_TTS_BF16_TWO_TERM = "none", "default" or a comma list of
+// lm.in_proj, lm.qkv, lm.out, lm.ff2, flow.cond, flow.ada, flow.in_proj, flow.final.lin.
+std::set<std::string> two_term_families(Precision prec, bool int8_flow_blocks) {
+    static const char* known[] = {"lm.in_proj", "lm.qkv", "lm.out", "lm.ff2", "flow.cond", "flow.ada", "flow.in_proj", "flow.final.lin"};
+    std::set<std::string> out;
+    if (prec == Precision::FP32) return out;
+    const char* e = std::getenv("POCKET_TTS_BF16_TWO_TERM");
+    std::string v = e ? e : "default";
+    if (v == "none" || v == "0") return out;
+    if (v == "default" || v == "1") v = "lm.in_proj,flow.cond,flow.ada,flow.in_proj,flow.final.lin";
+    size_t at = 0;
+    while (at <= v.size()) {
+        const size_t c = v.find(',', at);
+        const std::string name = v.substr(at, c == std::string::npos ? std::string::npos : c - at);
+        at = c == std::string::npos ? v.size() + 1 : c + 1;
+        if (name.empty()) continue;
+        bool ok = false;
+        for (const char* k : known) ok = ok || name == k;
+        if (!ok) throw std::runtime_error("POCKET_TTS_BF16_TWO_TERM: unknown matrix family " + name);
+        out.insert(name);
+    }
+    if (prec == Precision::INT8) {   // these are int8 matrices there
+        out.erase("lm.qkv"); out.erase("lm.out"); out.erase("lm.ff2");
+        // the persistent head with int8 blocks has no LDS left for second planes of its projections
+        if (int8_flow_blocks) { out.erase("flow.in_proj"); out.erase("flow.final.lin"); }
+    }
+    return out;
+}
 
 Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec) {
     const Spec& s = spec_;
@@ -157,6 +204,29 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     const bool q8 = prec_ == Precision::INT8;
     lm_wtype = q8 ? W_I8 : flow_wtype;
     flow_block_wtype = (q8 && s.flow_dim % 256 == 0) ? W_I8 : flow_wtype;   // narrower heads keep bf16 blocks
+    two_term = two_term_families(prec_, flow_block_wtype == W_I8);
+    // second plane of a two-term matrix in the fragment-major layout of the skinny / flow kernels
+    auto packed_lo = [&](const float* W, int N, int K) -> const void* {
+        std::vector<float> lo(static_cast<size_t>(N) * K);
+        for (size_t i = 0; i < lo.size(); ++i) lo[i] = W[i] - bf16_part(W[i]);
+        auto bytes = pack_flow_weight(lo.data(), N, K, W_BF16);
+        extra_.emplace_back(bytes.size());
+        sync_copy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice);
+        return extra_.back().p;
+    };
+    auto packed_lo_named = [&](const std::string& name) -> const void* {
+        const HostTensor& t = pack.get(name);
+        return packed_lo(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]));
+    };
+    // ... and row-major, beside the bf16 blob's first plane, for the tiled GEMM of long prefill passes
+    auto rowmajor_lo = [&](const std::string& name) {
+        const HostTensor& t = pack.get(name);
+        std::vector<uint16_t> lo(t.numel());
+        for (size_t i = 0; i < lo.size(); ++i) lo[i] = f32_to_bf16(t.data[i] - bf16_part(t.data[i]));
+        extra_.emplace_back(lo.size() * 2);
+        sync_copy(extra_.back().p, lo.data(), lo.size() * 2, hipMemcpyHostToDevice);
+        split_[name] = {static_cast<const unsigned char*>(blob_lp_.p) + entries_[name].off_lp, extra_.back().p};
+    };
     // int8 form of a matrix: fragment-major int8 values + per-output-row scales, both uploaded
     auto packed_q8 = [&](const std::string& name, const float*& scale_dev) -> const void* {
         const HostTensor& t = pack.get(name);
@@ -189,6 +259,7 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     flow_in_packed = packed("flow.in_proj.w");
     flow_out_packed = packed("flow.final.lin.w");
     flow_cond_packed = packed("flow.cond.w");
+    if (two_term.count("flow.cond")) flow_cond_packed_lo = packed_lo_named("flow.cond.w");
     {
         const HostTensor& t = pack.get("lm.in_proj.w");
         if (t.shape[0] % 16 == 0 && t.shape[1] % (flow_wtype == W_BF16 ? 32 : 16) == 0) lm_in_packed = packed("lm.in_proj.w");
@@ -200,6 +271,7 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
             extra_.emplace_back(bytes.size());
             sync_copy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice);
             ada_packed = extra_.back().p;
+            if (two_term.count("flow.ada")) ada_packed_lo = packed_lo(reinterpret_cast<const float*>(host.data() + ada_off_f32), mod_width, C);
         }
     }
     // decoder matrices whose products are short and deep when one utterance streams (5 frames = 80 rows): the Mimi
@@ -270,6 +342,9 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
             pl.ff1 = packed_q8(p + "ff1.w", pl.s_ff1); pl.ff2 = packed_q8(p + "ff2.w", pl.s_ff2);
         } else {
             pl.qkv = packed(p + "qkv.w"); pl.out = packed(p + "out.w"); pl.ff1 = packed(p + "ff1.w"); pl.ff2 = packed(p + "ff2.w");
+            if (two_term.count("lm.qkv")) { pl.qkv_lo = packed_lo_named(p + "qkv.w"); rowmajor_lo(p + "qkv.w"); }
+            if (two_term.count("lm.out")) { pl.out_lo = packed_lo_named(p + "out.w"); rowmajor_lo(p + "out.w"); }
+            if (two_term.count("lm.ff2")) { pl.ff2_lo = packed_lo_named(p + "ff2.w"); rowmajor_lo(p + "ff2.w"); }
         }
         lm_packed.push_back(pl);
     }
@@ -292,6 +367,18 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     if (flow_wtype == W_BF16) {   // bf16 or int8 blocks (the int8 form keeps its scales in s_fc1 / s_fc2)
         flow_tabs.r_in = flow_in_packed; flow_tabs.r_out = flow_out_packed;
         flow_tabs.r_fc1 = flow_tabs.w_fc1; flow_tabs.r_fc2 = flow_tabs.w_fc2;
+        // second planes of the in / out projections: both or neither (a family that was not asked for gets a plane of zeros)
+        if (two_term.count("flow.in_proj") || two_term.count("flow.final.lin")) {
+            auto lo_or_zero = [&](const std::string& name, bool on) -> const void* {
+                if (on) return packed_lo_named(name);
+                const HostTensor& t = pack.get(name);
+                extra_.emplace_back(t.numel() * 2);
+                sync_fill(extra_.back().p, 0, t.numel() * 2);
+                return extra_.back().p;
+            };
+            flow_tabs.r_in_lo = lo_or_zero("flow.in_proj.w", two_term.count("flow.in_proj") != 0);
+            flow_tabs.r_out_lo = lo_or_zero("flow.final.lin.w", two_term.count("flow.final.lin") != 0);
+        }
     } else if (flow_wtype == W_F32 && C == 512 && s.latent == 32 && !std::getenv("POCKET_TTS_FLOW_F32_CHAIN")) {
         auto planes = [&](const std::string& name, const void*& hi_dev, const void*& lo_dev) {
             const HostTensor& t = pack.get(name);
@@ -347,7 +434,7 @@ DevWeight Model::w(const std::string& name) const {
     DevWeight d;
     d.N = static_cast<int>(e.shape[0]);
     d.K = static_cast<int>(e.shape[1]);
-    if (e.has_lp) {
+    if (e.has_lp && !(name == "lm.in_proj.w" && two_term.count("lm.in_proj"))) {   // that small matrix is simply used in f32
         d.p = static_cast<const unsigned char*>(blob_lp_.p) + e.off_lp;
         d.wtype = W_BF16;
     } else {
@@ -357,7 +444,10 @@ DevWeight Model::w(const std::string& name) const {
     auto fr = frag_.find(name);
     if (fr != frag_.end()) d.frag = fr->second;
     auto sp = split_.find(name);
-    if (sp != split_.end()) { d.f32 = d.p; d.p = sp->second.first; d.lo = sp->second.second; d.wtype = W_BF16; }
+    if (sp != split_.end()) {
+        d.f32 = static_cast<const unsigned char*>(blob_f32_.p) + e.off_f32;
+        d.p = sp->second.first; d.lo = sp->second.second; d.wtype = W_BF16;
+    }
     return d;
 }
 
@@ -971,7 +1061,7 @@ void Engine::lm_rows_skinny(Batch& b, int slot0, int nb, int rpb, float* X) {
         const TfLayer& w = hd_.lm[l];
         const Model::PackedLayer& pw = model_->lm_packed[l];
         SkinnyArgs q;
-        q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.wtype = wt; q.wscale = pw.s_qkv; q.M = M; q.N = 3 * D; q.K = D; q.C = b.qkv.f(); q.ldc = 3 * D;
+        q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.Wp2 = pw.qkv_lo; q.wtype = wt; q.wscale = pw.s_qkv; q.M = M; q.N = 3 * D; q.K = D; q.C = b.qkv.f(); q.ldc = 3 * D;
         launch_skinny_gemm(q, st);
         RopeAppendArgs r;
         const long long kv_off = static_cast<long long>(l) * layer_stride * (b.kv16 ? 2 : 4);
@@ -984,7 +1074,7 @@ void Engine::lm_rows_skinny(Batch& b, int slot0, int nb, int rpb, float* X) {
         at.M = M; at.d = D; at.heads = s.lm_heads; at.cap = b.lm_cap; at.window = 0;
         launch_attention(at, st);
         SkinnyArgs o;
-        o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.wtype = wt; o.wscale = pw.s_out; o.M = M; o.N = D; o.K = D; o.splits = s_out; o.P = b.pre_partial.f();
+        o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.Wp2 = pw.out_lo; o.wtype = wt; o.wscale = pw.s_out; o.M = M; o.N = D; o.K = D; o.splits = s_out; o.P = b.pre_partial.f();
         launch_skinny_gemm(o, st);
         AddNormArgs a1 = an;
         a1.P = b.pre_partial.f(); a1.splits = s_out; a1.colscale = w.ls1; a1.g = w.ln2g; a1.b = w.ln2b;
@@ -994,7 +1084,7 @@ void Engine::lm_rows_skinny(Batch& b, int slot0, int nb, int rpb, float* X) {
         f1.C = b.ff.f(); f1.ldc = F;
         launch_skinny_gemm(f1, st);
         SkinnyArgs f2;
-        f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.wtype = wt; f2.wscale = pw.s_ff2; f2.M = M; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.pre_partial.f();
+        f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.Wp2 = pw.ff2_lo; f2.wtype = wt; f2.wscale = pw.s_ff2; f2.M = M; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.pre_partial.f();
         launch_skinny_gemm(f2, st);
         AddNormArgs a2 = an;
         a2.P = b.pre_partial.f(); a2.splits = s_ff2; a2.colscale = w.ls2;
@@ -1051,7 +1141,7 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         const TfLayer& w = hd_.lm[l];
         const Model::PackedLayer& pw = model_->lm_packed[l];
         SkinnyArgs q;
-        q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.wtype = wt; q.wscale = pw.s_qkv; q.M = B; q.N = 3 * D; q.K = D;
+        q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.Wp2 = pw.qkv_lo; q.wtype = wt; q.wscale = pw.s_qkv; q.M = B; q.N = 3 * D; q.K = D;
         q.splits = s_qkv; q.P = b.qkv.f();   // K-slice slabs, summed where the attention kernel reads them
         if (preq) { q.A = nullptr; q.Aq = b.hq.as<signed char>(); q.ldaq = D; q.Ad = b.hd.f(); q.Mq = b.q_rows; }
         launch_skinny_gemm(q, b.st);
@@ -1064,7 +1154,7 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         if (preq) { at.out = nullptr; at.out_q = b.attq.as<signed char>(); at.out_d = b.attd.f(); at.Mq = b.q_rows; }
         launch_attn_decode(at, b.st);
         SkinnyArgs o;
-        o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.wtype = wt; o.wscale = pw.s_out; o.M = B; o.N = D; o.K = D; o.splits = s_out; o.P = b.partial.f();
+        o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.Wp2 = pw.out_lo; o.wtype = wt; o.wscale = pw.s_out; o.M = B; o.N = D; o.K = D; o.splits = s_out; o.P = b.partial.f();
         if (preq) { o.A = nullptr; o.Aq = b.attq.as<signed char>(); o.ldaq = D; o.Ad = b.attd.f(); o.Mq = b.q_rows; }
         launch_skinny_gemm(o, b.st);
         AddNormArgs a1 = an;
@@ -1079,7 +1169,7 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         }
         launch_skinny_gemm(f1, b.st);
         SkinnyArgs f2;
-        f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.wtype = wt; f2.wscale = pw.s_ff2; f2.M = B; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.partial.f();
+        f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.Wp2 = pw.ff2_lo; f2.wtype = wt; f2.wscale = pw.s_ff2; f2.M = B; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.partial.f();
         if (preq) { f2.A = nullptr; f2.Aq = b.ffq.as<signed char>(); f2.ldaq = F; f2.Ad = b.ffd.f(); f2.Mq = b.q_rows; }
         launch_skinny_gemm(f2, b.st);
         AddNormArgs a2 = an;
@@ -1145,7 +1235,7 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
     const int wt = model_->flow_wtype;
     const int cs = pick_splits(s.d_model, wt == W_BF16 ? 32 : 16);
     SkinnyArgs g;
-    g.A = cond_dev; g.lda = s.d_model; g.Wp = model_->flow_cond_packed; g.wtype = wt; g.M = B; g.N = C; g.K = s.d_model;
+    g.A = cond_dev; g.lda = s.d_model; g.Wp = model_->flow_cond_packed; g.Wp2 = model_->flow_cond_packed_lo; g.wtype = wt; g.M = B; g.N = C; g.K = s.d_model;
     g.splits = cs; g.P = fs.cemb;
     launch_skinny_gemm(g, st);
     FramePublish pub;
@@ -1156,6 +1246,7 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
     // the persistent head's counters start every call at zero; this launch (two boundaries ahead of the head) clears them
     FlowHeadArgs probe;
     probe.C = C; probe.L = s.latent; probe.blocks = s.flow_blocks; probe.steps = N; probe.B = B; probe.wtype = model_->flow_wtype;
+    probe.host_tabs = &model_->flow_tabs;
     probe.block_wtype = model_->flow_block_wtype; probe.ring_split = model_->flow_ring_split; probe.ring_ctl = fs.ctl; probe.ring_wg_budget = 224 / std::max(lanes_, 1);
     const bool ring = owns_ring_ && fs.ctl && flow_ring_supported(probe);
     const int cw = static_cast<int>(flow_ring_counter_word());
@@ -1164,7 +1255,7 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
     // (POCKET_TTS_ADA_F32_ROWS=1: f32 rows, converted and reordered by the product)
     SkinnyArgs m;
     if (model_->ada_packed) {
-        m.A = fs.ymod; m.lda = C; m.Wp = model_->ada_packed; m.wtype = wt; m.M = N * B; m.N = model_->mod_width; m.K = C;
+        m.A = fs.ymod; m.lda = C; m.Wp = model_->ada_packed; m.Wp2 = model_->ada_packed_lo; m.wtype = wt; m.M = N * B; m.N = model_->mod_width; m.K = C;
         m.bias = model_->ada_all_b; m.C = fs.mods; m.ldc = model_->mod_width;
         if (m.M > 128) { m.mtiles = 2; m.kchunk = 128; }   // measured at 640 x 10240 x 512: 32 us (64-row groups 39 us, tiled GEMM 66 us)
         const char* f32_rows = std::getenv("POCKET_TTS_ADA_F32_ROWS");

@@ -16,6 +16,7 @@
 #include <map>
 #include <mutex>
 #include <random>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -78,13 +79,19 @@ public:
     FlowHostTabs flow_tabs;      // per-block device pointers of the flow head (host arrays)
     const void *flow_in_packed = nullptr, *flow_out_packed = nullptr;  // fragment-major flow.in_proj.w / flow.final.lin.w
     // fragment-major copies of the weights the batched decode step streams (decode_kernels.hip)
-    struct PackedLayer { const void *qkv, *out, *ff1, *ff2; const float *s_qkv = nullptr, *s_out = nullptr, *s_ff1 = nullptr, *s_ff2 = nullptr; };
+    struct PackedLayer {
+        const void *qkv, *out, *ff1, *ff2;
+        const float *s_qkv = nullptr, *s_out = nullptr, *s_ff1 = nullptr, *s_ff2 = nullptr;
+        const void *qkv_lo = nullptr, *out_lo = nullptr, *ff2_lo = nullptr;   // second planes of two-term bf16 matrices (null: one term)
+    };
+    std::set<std::string> two_term;   // matrix families held as two bf16 terms (see two_term_families in engine.cpp)
     int lm_wtype = W_F32;        // weight type of lm_packed (W_I8 in int8 mode)
     int flow_block_wtype = W_F32;
     bool flow_ring_split = false;   // float engine: flow_tabs carries two-term bf16 planes for the persistent flow head
     std::vector<PackedLayer> lm_packed;
     const void* enc_ds_packed = nullptr;   // voice encoder's down-sampling matrix, fragment-major f32 (K-slice product of short clips)
     const void* flow_cond_packed = nullptr;
+    const void *flow_cond_packed_lo = nullptr, *ada_packed_lo = nullptr;   // second planes (two-term families)
     const void* lm_in_packed = nullptr;  // LM input projection, fragment-major (null when its shape does not tile)
     const void* ada_packed = nullptr;   // stacked adaLN matrix, fragment-major (null when its shape does not tile)
     int flow_wtype = W_F32;

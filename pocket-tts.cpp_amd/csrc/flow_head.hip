@@ -101,6 +101,16 @@ __device__ __forceinline__ void mma_frag(const WT* A0, const WT* A1, int lda, in
     }
 }
 
+// acc += A_hi[16][k0 .. k0+32) * (second term of a two-term bf16 weight fragment); issued in front of mma_frag, as the
+// persistent form does
+template <typename WT>
+__device__ __forceinline__ void mma_frag_w2(const WT* A0, int lda, int k0, const uint4 wl, f32x4& acc, int lane) {
+    if constexpr (!std::is_same<WT, float>::value) {
+        const bf16x8 hi = *(const bf16x8*)(A0 + (lane & 15) * lda + k0 + 8 * (lane >> 4));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, __builtin_bit_cast(bf16x8, wl), acc, 0, 0, 0);
+    }
+}
+
 template <bool ONE>
 __device__ __forceinline__ void one_row_finish(f32x4& acc) {
     if constexpr (ONE) {
@@ -281,6 +291,7 @@ struct FlowBlockArgs {
     const float* prev_b2 = nullptr;   // fc2 bias of the previous block
     int first = 0, blk = 0;
     const void* w_in = nullptr; const float* b_in = nullptr;
+    const void* w_in_lo = nullptr; const void* w_out_lo = nullptr;   // bf16 weights: second terms of the in / out projections (null: one term)
     const void* w1 = nullptr; const float* b1 = nullptr; const void* w2 = nullptr;
     const float* s1 = nullptr; const float* s2 = nullptr;   // int8 blocks: per-output-column scales of fc1 / fc2
     const float* ln_g = nullptr; const float* ln_b = nullptr;
@@ -387,9 +398,13 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
                                              a.fin_b2, row0, nrows, wave, lane);
                 }
                 const int to = wave % NTL, kpo = wave / NTL;
-                uint4 wo[KSP];
+                uint4 wo[KSP], wol[KSP];
+                const bool out2 = !std::is_same<WT, float>::value && a.w_out_lo != nullptr;   // uniform
 #pragma unroll
-                for (int ks = 0; ks < KSP; ++ks) wo[ks] = ((const uint4*)a.w_out)[((long long)to * KS + kpo * KSP + ks) * 64 + lane];
+                for (int ks = 0; ks < KSP; ++ks) {
+                    wo[ks] = ((const uint4*)a.w_out)[((long long)to * KS + kpo * KSP + ks) * 64 + lane];
+                    wol[ks] = ((const uint4*)(out2 ? a.w_out_lo : a.w_out))[((long long)to * KS + kpo * KSP + ks) * 64 + lane];
+                }
                 if (live) {
                     float4 hf[RPW][RM::NP];
                     residual_finish<C, G, RPW>(hf, rf);
@@ -398,7 +413,10 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
                 __syncthreads();
                 f32x4 acco = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < KSP; ++ks) mma_frag<WT, ONE>(A0, A1, lda, (kpo * KSP + ks) * KSTEP, wo[ks], acco, lane);
+                for (int ks = 0; ks < KSP; ++ks) {
+                    if (out2) mma_frag_w2<WT>(A0, lda, (kpo * KSP + ks) * KSTEP, wol[ks], acco, lane);
+                    mma_frag<WT, ONE>(A0, A1, lda, (kpo * KSP + ks) * KSTEP, wo[ks], acco, lane);
+                }
                 one_row_finish<ONE>(acco);
                 float* redo = hbuf;                            // [waves][256]; hbuf is not in use yet
                 *(f32x4*)(redo + wave * 256 + lane * 4) = acco;
@@ -430,13 +448,17 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
             }
         }
         __syncthreads();
-        uint4 wi[T2][KSL];
+        uint4 wi[T2][KSL], wil[T2][KSL];
         float bin[T2];
+        const bool in2 = !std::is_same<WT, float>::value && a.w_in_lo != nullptr;   // uniform
 #pragma unroll
         for (int i = 0; i < T2; ++i) {
             const int t = (wave + kFlowWaves * i) < NT ? (wave + kFlowWaves * i) : NT - 1;
 #pragma unroll
-            for (int ks = 0; ks < KSL; ++ks) wi[i][ks] = ((const uint4*)a.w_in)[((long long)t * KSL + ks) * 64 + lane];
+            for (int ks = 0; ks < KSL; ++ks) {
+                wi[i][ks] = ((const uint4*)a.w_in)[((long long)t * KSL + ks) * 64 + lane];
+                wil[i][ks] = ((const uint4*)(in2 ? a.w_in_lo : a.w_in))[((long long)t * KSL + ks) * 64 + lane];
+            }
             bin[i] = a.b_in[t * 16 + ccol];
         }
         request_fc1(0);
@@ -445,7 +467,10 @@ __global__ __launch_bounds__(kFlowThreads) void flow_block_kernel(FlowBlockArgs 
             const int t = wave + kFlowWaves * i;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KSL; ++ks) mma_frag<WT, ONE>(X0, X1, ldx, ks * KSTEP, wi[i][ks], acc, lane);
+            for (int ks = 0; ks < KSL; ++ks) {
+                if (in2) mma_frag_w2<WT>(X0, ldx, ks * KSTEP, wil[i][ks], acc, lane);
+                mma_frag<WT, ONE>(X0, X1, ldx, ks * KSTEP, wi[i][ks], acc, lane);
+            }
             one_row_finish<ONE>(acc);
             if (t < NT) {
                 const int c = t * 16 + ccol;
@@ -778,6 +803,7 @@ struct FlowFinalArgs {
     float* x_out = nullptr;                                            // [B][L]
     float* latents = nullptr; const int* lat_step = nullptr; int max_frames = 0;   // optional: also file x_out under frame *lat_step + x_step_bias
     const void* w_out = nullptr; const float* b_out = nullptr;
+    const void* w_out_lo = nullptr;   // bf16 weights: second term of the output projection (null: one term)
     int B = 0, blocks = 0, mod_width = 0, rpg = 16;
     float eps = 1e-6f, dt = 0.f;
 };
@@ -811,9 +837,13 @@ __global__ __launch_bounds__(kFlowThreads) void flow_final_kernel(FlowFinalArgs 
         residual_load<C, G, RPW>(rres, a.h_prev, a.part_prev, (long long)a.B * C, a.mods + (a.blocks - 1) * 3 * C + 2 * C, a.mod_width, a.prev_b2,
                                  row0, nrows, wave, lane);
     }
-    uint4 wo[KSP];
+    uint4 wo[KSP], wol[KSP];
+    const bool out2 = !std::is_same<WT, float>::value && a.w_out_lo != nullptr;   // uniform
 #pragma unroll
-    for (int ks = 0; ks < KSP; ++ks) wo[ks] = ((const uint4*)a.w_out)[((long long)t * KS + kp * KSP + ks) * 64 + lane];
+    for (int ks = 0; ks < KSP; ++ks) {
+        wo[ks] = ((const uint4*)a.w_out)[((long long)t * KS + kp * KSP + ks) * 64 + lane];
+        wol[ks] = ((const uint4*)(out2 ? a.w_out_lo : a.w_out))[((long long)t * KS + kp * KSP + ks) * 64 + lane];
+    }
     if (live) {
         float4 h[RPW][RM::NP];
         residual_finish<C, G, RPW>(h, rres);
@@ -823,7 +853,10 @@ __global__ __launch_bounds__(kFlowThreads) void flow_final_kernel(FlowFinalArgs 
     __syncthreads();
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < KSP; ++ks) mma_frag<WT, ONE>(A0, A1, lda, (kp * KSP + ks) * KSTEP, wo[ks], acc, lane);
+    for (int ks = 0; ks < KSP; ++ks) {
+        if (out2) mma_frag_w2<WT>(A0, lda, (kp * KSP + ks) * KSTEP, wol[ks], acc, lane);
+        mma_frag<WT, ONE>(A0, A1, lda, (kp * KSP + ks) * KSTEP, wo[ks], acc, lane);
+    }
     one_row_finish<ONE>(acc);
     *(f32x4*)(red + wave * 256 + lane * 4) = acc;
     __syncthreads();
@@ -935,6 +968,8 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
     int cur = 0;
     if (a.probe_a) (void)hipEventRecord(a.probe_a, s);   // the probe brackets the whole chain: steps * (blocks + 1) launches
     const bool fuse = FUSE && !q8;
+    // bf16 matrices whose in / out projections carry second terms (not the int8 blocks' kernel, not the float chain)
+    const bool io2 = std::is_same<WT, __bf16>::value && !q8 && a.wtype == W_BF16 && tabs.r_in_lo && tabs.r_out_lo;
     float* xb[2] = {pb[1] + (size_t)kMaxFlowSplit * B * C, pb[1] + (size_t)kMaxFlowSplit * B * C + (size_t)B * L};   // x after odd / even steps
     for (int j = 0; j < a.steps; ++j) {
         const float* mods_j = a.mods + (size_t)j * B * a.mod_width;
@@ -950,6 +985,7 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
             fb.mods = mods_j; fb.prev_b2 = blk ? tabs.b_fc2[blk - 1] : nullptr;
             fb.first = blk == 0; fb.blk = blk;
             fb.w_in = a.w_in; fb.b_in = a.b_in; fb.w1 = tabs.w_fc1[blk]; fb.b1 = tabs.b_fc1[blk]; fb.w2 = tabs.w_fc2[blk];
+            if (io2) { fb.w_in_lo = tabs.r_in_lo; fb.w_out_lo = tabs.r_out_lo; }
             fb.ln_g = tabs.ln_g[blk]; fb.ln_b = tabs.ln_b[blk];
             if (q8) { fb.s1 = tabs.s_fc1[blk]; fb.s2 = tabs.s_fc2[blk]; }
             fb.B = B; fb.mod_width = a.mod_width; fb.eps = a.eps; fb.rpg = rpg;
@@ -973,6 +1009,7 @@ static void run_chain(const FlowHeadArgs& a, hipStream_t s, int rpg) {
         ff.h_prev = hb[cur ^ 1]; ff.part_prev = pb[cur ^ 1]; ff.mods = mods_j; ff.prev_b2 = tabs.b_fc2[a.blocks - 1];
         ff.x_in = x_in; ff.x_stride = x_stride; ff.x_out = a.x_out;
         if (j == 0) { ff.x_step = a.x0_step; ff.x_step_stride = a.x0_step_stride; } ff.w_out = a.w_out; ff.b_out = a.b_out;
+        if (io2) ff.w_out_lo = tabs.r_out_lo;
         ff.x_step_bias = a.x0_step_bias; ff.step_ring = a.step_ring;
         if (j + 1 == a.steps && a.latents) { ff.latents = a.latents; ff.lat_step = a.x0_step; ff.max_frames = a.max_frames; }
         ff.B = B; ff.blocks = a.blocks; ff.mod_width = a.mod_width; ff.eps = a.eps; ff.dt = 1.0f / (float)a.steps; ff.rpg = rpg;

@@ -188,8 +188,12 @@ struct FlowRingArgs {
 // engine's matrices to ~16 mantissa bits) and every tile takes a third MFMA; the register budget then allows G = 8 only.
 // Q8: the residual blocks' matrices are int8 with per-column scales and their inputs are quantised per row and 64-wide block
 // (v_mfma_i32_16x16x64_i8, half the matrix registers); the in / out projections stay bf16.
-template <int RPG, int G, bool WS, bool Q8>
+// IO2: the in / out projections alone come as two bf16 terms (the bf16 engine: those two small matrices sit at the ends of
+// every Euler step and their storage rounding reaches the latent directly; their second planes live in block 0's LDS).
+template <int RPG, int G, bool WS, bool Q8, bool IO2 = false>
 __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
+    constexpr bool WIO = WS || IO2;
+    static_assert(!(WS && IO2) && !(Q8 && IO2), "flow ring: IO2 is the bf16 form with two-term projections");
     constexpr int NT1 = NT / G, NW1 = NT1 / kWaves, KS2 = KS / G, CS = C / G, LDA2 = lda2_of(G);
     constexpr int KS2Q = KSQ / G, LDSQ = CS + 16;
     static_assert(NW1 >= 1 && NW1 * kWaves == NT1 && KS2 * G == KS, "flow ring: slices must divide the tiles of fc1 and the k-steps of fc2");
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
     if (first_blk) {
         for (int i = tid; i < NT * 64; i += kThreads) win_l[i] = ((const uint4*)a.w_in)[i];
         for (int i = tid; i < NTL * KS * 64; i += kThreads) wout_l[i] = ((const uint4*)a.w_out)[i];
-        if constexpr (WS) {
+        if constexpr (WIO) {
             for (int i = tid; i < NT * 64; i += kThreads) win_lo[i] = ((const uint4*)a.w_in_lo)[i];
             for (int i = tid; i < NTL * KS * 64; i += kThreads) wout_lo[i] = ((const uint4*)a.w_out_lo)[i];
         }
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
 #pragma unroll
             for (int ks = 0; ks < KSP; ++ks) {
                 const int wi = (to * KS + kpo * KSP + ks) * 64 + lane;
-                mma2<WS>(fh[ks], fl[ks], wout_l[wi], WS ? wout_lo[wi] : wout_l[wi], acco);
+                mma2<WIO>(fh[ks], fl[ks], wout_l[wi], WIO ? wout_lo[wi] : wout_l[wi], acco);
             }
         }
         *(f32x4*)(hbuf + wave * 256 + lane * 4) = acco;
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
                 for (int i = 0; i < TI; ++i) {
                     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
                     const int wi = (wave + kWaves * i) * 64 + lane;
-                    mma2<WS>(xh, xl, win_l[wi], WS ? win_lo[wi] : win_l[wi], acc);
+                    mma2<WIO>(xh, xl, win_l[wi], WIO ? win_lo[wi] : win_l[wi], acc);
                     const int c = (wave + kWaves * i) * 16 + ccol;
                     hbuf[lq * C + c] = own_row(acc, lq) + bin[i];
                 }
@@ -644,7 +648,12 @@ static int ring_slices(bool split) {
 }
 
 static void flow_ring_shape(int B, int blocks, int budget, bool split, int& rpg, int& replicas);
-static size_t ring_smem(int rpg, int ngroups, int replicas, bool split, bool q8);
+static size_t ring_smem(int rpg, int ngroups, int replicas, bool split, bool q8, bool io2);
+
+// bf16 blocks with the second planes of the in / out projections present: those two products take the third MFMA
+static bool ring_io2(const FlowHeadArgs& a, bool split, bool q8) {
+    return !split && !q8 && a.host_tabs && a.host_tabs->r_in_lo && a.host_tabs->r_out_lo;
+}
 
 bool flow_ring_supported(const FlowHeadArgs& a) {
     if (std::getenv("FLOW_HEAD_NO_RING")) return false;
@@ -658,7 +667,7 @@ bool flow_ring_supported(const FlowHeadArgs& a) {
     // the row groups a workgroup serves keep their x rows in LDS: many rows on few replicas may not fit (the launch chain runs then)
     int rpg = 4, replicas = 1;
     flow_ring_shape(a.B, a.blocks, a.ring_wg_budget, split, rpg, replicas);
-    return ring_smem(rpg, (a.B + rpg - 1) / rpg, replicas, split, bw == W_I8) <= 160 * 1024;
+    return ring_smem(rpg, (a.B + rpg - 1) / rpg, replicas, split, bw == W_I8, ring_io2(a, split, bw == W_I8)) <= 160 * 1024;
 }
 
 // Row-group height and replica count for B rows.  More replicas shorten each workgroup's queue of row groups; the
@@ -692,11 +701,11 @@ size_t flow_ring_ctl_bytes(int B, int blocks) {
 size_t flow_ring_err_word(int, int) { return 0; }
 size_t flow_ring_counter_word() { return kCtlStride; }
 
-static size_t ring_smem(int rpg, int ngroups, int replicas, bool split, bool q8) {
+static size_t ring_smem(int rpg, int ngroups, int replicas, bool split, bool q8, bool io2) {
     const int local = (ngroups + replicas - 1) / replicas;
     const int LDA2 = lda2_of(ring_slices(split));
     return (size_t)rpg * C * 4 + (size_t)2 * rpg * (LDA + LDA2 + LDX) * 2 + (size_t)kWaves * rpg * kTw * 4 + (size_t)local * rpg * L * 4 + 16 +
-           (q8 ? q8_lds_bytes(ring_slices(split)) : 0) + (size_t)(NT + NTL * KS) * 64 * 16 * (split ? 2 : 1);
+           (q8 ? q8_lds_bytes(ring_slices(split)) : 0) + (size_t)(NT + NTL * KS) * 64 * 16 * (split || io2 ? 2 : 1);
 }
 
 static void ring_lds_limit(const void* kernel) {
@@ -714,6 +723,8 @@ void flow_ring_prepare() {
     ring_lds_limit((const void*)flow_ring_kernel<4, 8, true, false>);
     ring_lds_limit((const void*)flow_ring_kernel<4, 8, false, true>);
     ring_lds_limit((const void*)flow_ring_kernel<4, 4, false, true>);
+    ring_lds_limit((const void*)flow_ring_kernel<4, 8, false, false, true>);
+    ring_lds_limit((const void*)flow_ring_kernel<4, 4, false, false, true>);
 }
 
 // The caller has zeroed a.ring_ctl (flow_ring_ctl_bytes) earlier on the same stream.
@@ -734,7 +745,8 @@ void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s) {
     if (split && (!t.r_in_lo || !t.r_out_lo || (int)t.r_fc1_lo.size() < a.blocks || (int)t.r_fc2_lo.size() < a.blocks))
         throw std::runtime_error("flow ring: second matrix planes missing");
     r.w_in = t.r_in; r.b_in = a.b_in; r.w_out = t.r_out; r.b_out = a.b_out;
-    r.w_in_lo = split ? t.r_in_lo : nullptr; r.w_out_lo = split ? t.r_out_lo : nullptr;
+    const bool io2 = ring_io2(a, split, q8);
+    r.w_in_lo = split || io2 ? t.r_in_lo : nullptr; r.w_out_lo = split || io2 ? t.r_out_lo : nullptr;
     for (int i = 0; i < a.blocks; ++i) {
         r.w1[i] = t.r_fc1[i]; r.w2[i] = t.r_fc2[i]; r.b1[i] = t.b_fc1[i]; r.b2[i] = t.b_fc2[i]; r.ln_g[i] = t.ln_g[i]; r.ln_b[i] = t.ln_b[i];
         r.w1l[i] = split ? t.r_fc1_lo[i] : nullptr; r.w2l[i] = split ? t.r_fc2_lo[i] : nullptr;
@@ -748,7 +760,7 @@ void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s) {
     r.ctl = a.ring_ctl;
     r.eps = a.eps; r.dt = 1.0f / (float)a.steps;
     r.stamps = a.cycle_probe;
-    const size_t smem = ring_smem(rpg, r.ngroups, replicas, split, q8);
+    const size_t smem = ring_smem(rpg, r.ngroups, replicas, split, q8, io2);
     if (smem > 160 * 1024) throw std::runtime_error("flow ring: LDS request too large");
     const int G = ring_slices(split);
     const int grid = replicas * a.blocks * G;
@@ -756,6 +768,8 @@ void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s) {
     if (split) hipLaunchKernelGGL((flow_ring_kernel<4, 8, true, false>), dim3(grid), dim3(kThreads), smem, s, r);
     else if (q8 && G == 8) hipLaunchKernelGGL((flow_ring_kernel<4, 8, false, true>), dim3(grid), dim3(kThreads), smem, s, r);
     else if (q8) hipLaunchKernelGGL((flow_ring_kernel<4, 4, false, true>), dim3(grid), dim3(kThreads), smem, s, r);
+    else if (io2 && G == 8) hipLaunchKernelGGL((flow_ring_kernel<4, 8, false, false, true>), dim3(grid), dim3(kThreads), smem, s, r);
+    else if (io2) hipLaunchKernelGGL((flow_ring_kernel<4, 4, false, false, true>), dim3(grid), dim3(kThreads), smem, s, r);
     else if (G == 8) hipLaunchKernelGGL((flow_ring_kernel<4, 8, false, false>), dim3(grid), dim3(kThreads), smem, s, r);
     else hipLaunchKernelGGL((flow_ring_kernel<4, 4, false, false>), dim3(grid), dim3(kThreads), smem, s, r);
     if (a.probe_b) (void)hipEventRecord(a.probe_b, s);

@@ -245,6 +245,7 @@ std::vector<unsigned char> pack_q8_layout(const signed char* q, int N, int K);
 struct SkinnyArgs {
     const float* A = nullptr; int lda = 0;
     const void* Wp = nullptr; int wtype = W_F32;
+    const void* Wp2 = nullptr;       // W_BF16 only: second plane of a two-term matrix, bf16(W - bf16(W)), same layout; a third MFMA per fragment
     int M = 0, N = 0, K = 0, splits = 1;
     const float* bias = nullptr; int act = ACT_NONE;
     float* C = nullptr; int ldc = 0;

@@ -344,11 +344,30 @@ def bf16_round(a: np.ndarray) -> np.ndarray:
     return u.astype(np.uint32).view(np.float32).reshape(a.shape)
 
 
-def bf16_model(weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+# Matrix families the bf16 engine keeps as two bf16 terms (~16 mantissa bits, float-grade) by default; the int8 engine
+# keeps the first three (its LM layer matrices are int8 and its flow head has no room for second planes).
+# Mirrors two_term_families() in csrc/engine.cpp.
+TWO_TERM_DEFAULT = ("lm.in_proj", "flow.cond", "flow.ada", "flow.in_proj", "flow.final.lin")
+
+
+def in_family(name: str, family: str) -> bool:
+    if family in ("lm.in_proj", "flow.cond", "flow.in_proj", "flow.final.lin"):
+        return name == family + ".w"
+    if family == "flow.ada":
+        return name.startswith("flow.") and name.endswith(".ada.w")
+    if family in ("lm.qkv", "lm.out", "lm.ff1", "lm.ff2"):
+        return name.startswith("lm.l") and name.endswith("." + family[3:] + ".w")
+    raise ValueError(family)
+
+
+def bf16_model(weights: Dict[str, np.ndarray], two_term=TWO_TERM_DEFAULT) -> Dict[str, np.ndarray]:
     """The model the bf16 engine actually holds: matrix weights rounded to bf16, everything else
     (biases, norms, embedding table, depthwise/1-channel convs, EOS head, time-embedding MLP, voice encoder)
-    left in float32."""
+    left in float32, and so are the families held as two bf16 terms (their 2^-17 residue is below float32
+    accumulation noise).  two_term=() gives every matrix rounded."""
     def rounded(k):
+        if any(in_family(k, f) for f in two_term):
+            return False
         return k.endswith(".w") and k not in F32_ONLY_WEIGHTS and not k.startswith(F32_ONLY_PREFIXES)
     return {k: (bf16_round(v) if rounded(k) else v) for k, v in weights.items()}
 
@@ -364,8 +383,8 @@ def is_int8_weight(name: str, flow_dim: int = 512) -> bool:
 def int8_model(weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     """Weight set for checking the int8 engine: like bf16_model, except that the matrices the engine quantises
     to int8 stay float32 here (both sides derive the int8 values and scales from the same float32 numbers)."""
-    q = bf16_model(weights)
     flow_dim = weights["flow.in_proj.w"].shape[0]
+    q = bf16_model(weights, two_term=TWO_TERM_DEFAULT[:3] if flow_dim % 256 == 0 else TWO_TERM_DEFAULT)
     for k, v in weights.items():
         if is_int8_weight(k, flow_dim):
             q[k] = v
