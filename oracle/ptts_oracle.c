@@ -128,19 +128,29 @@ void ptts_oracle_dims(const Oracle *o, int *dims) {
 
 static void q8_register(const float *W, int N, int K);
 
-/* Switches this oracle's LM-layer and flow-block matrices to the int8 scheme described at linear_q8. */
-void ptts_oracle_enable_q8(Oracle *o) {
+/* Switches the selected families of this oracle's LM-layer and flow-block matrices to the int8 scheme described at
+ * linear_q8.  mask bits: 1 qkv, 2 out, 4 ff1, 8 ff2 (LM layers), 16 fc1, 32 fc2 (flow blocks). */
+void ptts_oracle_enable_q8_some(Oracle *o, int mask) {
     const Spec *s = &o->s;
     const char *lm[4] = {"qkv.w", "out.w", "ff1.w", "ff2.w"};
     const int lmN[4] = {3 * s->d_model, s->d_model, s->lm_ffn, s->d_model};
     const int lmK[4] = {s->d_model, s->d_model, s->d_model, s->lm_ffn};
     for (int l = 0; l < s->lm_layers; ++l)
-        for (int j = 0; j < 4; ++j) q8_register(tensorf(o, "%s%d.%s", "lm.l", l, lm[j]), lmN[j], lmK[j]);
+        for (int j = 0; j < 4; ++j)
+            if (mask & (1 << j)) q8_register(tensorf(o, "%s%d.%s", "lm.l", l, lm[j]), lmN[j], lmK[j]);
     for (int b = 0; b < s->flow_blocks && s->flow_dim % 256 == 0; ++b) {   /* narrower heads keep bf16 blocks */
-        q8_register(tensorf(o, "%s%d.%s", "flow.b", b, "fc1.w"), s->flow_dim, s->flow_dim);
-        q8_register(tensorf(o, "%s%d.%s", "flow.b", b, "fc2.w"), s->flow_dim, s->flow_dim);
+        if (mask & 16) q8_register(tensorf(o, "%s%d.%s", "flow.b", b, "fc1.w"), s->flow_dim, s->flow_dim);
+        if (mask & 32) q8_register(tensorf(o, "%s%d.%s", "flow.b", b, "fc2.w"), s->flow_dim, s->flow_dim);
     }
 }
+
+/* ... all of them: the int8 engine's scheme. */
+void ptts_oracle_enable_q8(Oracle *o) { ptts_oracle_enable_q8_some(o, 63); }
+
+/* Attribution knob (tools/int8_attribution.py): which side of an int8 product is quantised.  3 = both (the engine's
+ * scheme, the default), 1 = weights only (activations stay float32), 2 = activations only (weights stay float32). */
+static int g_q8_parts = 3;
+void ptts_oracle_set_q8_parts(int parts) { g_q8_parts = parts; }
 
 static float dotf(const float *a, const float *b, int n) {
     float acc[16] = {0};
@@ -207,8 +217,20 @@ static void q8_forget(const unsigned char *lo, const unsigned char *hi) {
     g_nq8 = w;
 }
 
+static float dotf(const float *a, const float *b, int n);
+
 static void linear_q8(float *Y, int ldy, const float *X, int ldx, const Q8Entry *e, const float *bias, int M) {
     const int N = e->N, K = e->K, KB = K / 64;
+    if (g_q8_parts == 1) {   /* weights only: the float dot product with the de-quantised row */
+#pragma omp parallel for schedule(static) if ((long)M * N * K > 400000)
+        for (int n = 0; n < N; ++n) {
+            float *w = (float *)malloc((size_t)K * sizeof(float));
+            for (int k = 0; k < K; ++k) w[k] = (float)e->q[(size_t)n * K + k] * e->sw[n];
+            for (int m = 0; m < M; ++m) Y[(long)m * ldy + n] = dotf(X + (long)m * ldx, w, K) + (bias ? bias[n] : 0.f);
+            free(w);
+        }
+        return;
+    }
 #pragma omp parallel for schedule(static) if ((long)M * N * K > 400000)
     for (int m = 0; m < M; ++m) {
         int8_t *qx = (int8_t *)malloc((size_t)K);
@@ -226,7 +248,17 @@ static void linear_q8(float *Y, int ldy, const float *X, int ldx, const Q8Entry 
                 qx[kb * 64 + k] = (int8_t)r;
             }
         }
-        for (int n = 0; n < N; ++n) {
+        for (int n = 0; n < N && g_q8_parts == 2; ++n) {   /* activations only: quantised row against the float32 weights */
+            const float *wf = e->W + (size_t)n * K;
+            float acc = 0.f;
+            for (int kb = 0; kb < KB; ++kb) {
+                float fs = 0.f;
+                for (int k = 0; k < 64; ++k) fs += (float)qx[kb * 64 + k] * wf[kb * 64 + k];
+                acc += fs * d[kb];
+            }
+            Y[(long)m * ldy + n] = acc + (bias ? bias[n] : 0.f);
+        }
+        for (int n = 0; n < N && g_q8_parts != 2; ++n) {
             const int8_t *qw = e->q + (size_t)n * K;
             float acc = 0.f;
             for (int kb = 0; kb < KB; ++kb) {

@@ -164,8 +164,8 @@ def test_two_rank_job_reduction_over_gloo(tmp_path):
         time.sleep(0.05 * (rank + 1))
         ptts_shard.barrier(dist, torch.device("cpu"))
         dt = 0.1 * (rank + 1)
-        dt_max, units = ptts_shard.reduce_job(dt, sum(costs[i] for i in mine), dist, torch.device("cpu"))
-        json.dump(dict(rank=rank, mine=mine, dt_max=dt_max, units=units), open({str(tmp_path)!r} + f"/out{{rank}}.json", "w"))
+        dt_max, units, ranks = ptts_shard.reduce_job(dt, sum(costs[i] for i in mine), dist, torch.device("cpu"))
+        json.dump(dict(rank=rank, mine=mine, dt_max=dt_max, units=units, ranks=ranks), open({str(tmp_path)!r} + f"/out{{rank}}.json", "w"))
         dist.destroy_process_group()
     """))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
@@ -176,3 +176,52 @@ def test_two_rank_job_reduction_over_gloo(tmp_path):
     assert sorted(r0["mine"] + r1["mine"]) == list(range(7)) and not set(r0["mine"]) & set(r1["mine"])
     assert r0["dt_max"] == r1["dt_max"] == pytest.approx(0.2)
     assert r0["units"] == r1["units"] == 977.0
+    assert r0["ranks"] == r1["ranks"] == 2
+
+
+def test_spawn_plan_exports_what_a_launcher_would():
+    import ptts_shard
+    plan = ptts_shard.spawn_plan(4, ["bench.py", "--gpus", "4"], 29777, base_env={"KEEP": "1", "RANK": "9"})
+    assert len(plan) == 4
+    for r, (env, cmd) in enumerate(plan):
+        assert env["RANK"] == env["LOCAL_RANK"] == str(r) and env["WORLD_SIZE"] == "4"
+        assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "29777" and env["KEEP"] == "1"
+        assert cmd[0] == sys.executable and cmd[1:] == ["bench.py", "--gpus", "4"]
+    with pytest.raises(ValueError):
+        ptts_shard.spawn_plan(0, [], 1)
+
+
+def test_launch_ranks_runs_every_rank_and_relays_rank_zero(tmp_path, capfd):
+    """The launcher behind `bench.py --gpus N`: two ranks over gloo here (no GPU is opened), rank 0's line comes back on
+    standard output; a failing rank makes the launcher return non-zero and stops the other."""
+    import ptts_shard
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent(f"""
+        import json, os, sys, time
+        sys.path.insert(0, {os.path.join(ROOT, 'pocket-tts.cpp_amd', 'pyhost')!r})
+        import torch.distributed as dist
+        import ptts_shard
+        rank, local_rank, world = ptts_shard.env_ranks()
+        if len(sys.argv) > 1 and sys.argv[1] == "fail" and rank == 1:
+            sys.exit(3)
+        if len(sys.argv) > 1 and sys.argv[1] == "fail":
+            time.sleep(60)
+        dist.init_process_group("gloo")
+        dt_max, units, ranks = ptts_shard.reduce_job(0.5 + rank, 10.0, dist)
+        if rank == 0:
+            print(json.dumps(dict(n_gpus=ranks, units=units, dt_max=dt_max)), flush=True)
+        dist.destroy_process_group()
+    """))
+    assert ptts_shard.launch_ranks(2, [str(script)], timeout_s=200, gpus_visible=2) == 0
+    out = capfd.readouterr().out.strip().splitlines()[-1]
+    import json
+    assert json.loads(out) == dict(n_gpus=2, units=20.0, dt_max=1.5)
+    assert ptts_shard.launch_ranks(2, [str(script), "fail"], timeout_s=200, gpus_visible=2) == 1
+    assert "rank 1 exited with 3" in capfd.readouterr().err
+
+
+def test_bench_refuses_more_ranks_than_visible_gpus():
+    """`python bench.py --gpus 2` with fewer than two GPUs visible fails loudly instead of timing one GPU."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--size", "tiny"], capture_output=True, text=True, timeout=240,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 2 and "64 GPUs requested" in r.stderr and r.stdout.strip() == ""
