@@ -130,11 +130,13 @@ POCKET_TTS_API unsigned long long ptts_flow_euler_noalloc_capacity(void);
  * with the state carried in `state`                                 (src/pocket_tts.cpp:463-543). */
 POCKET_TTS_API int ptts_mimi_decode(PocketTTSHandle handle, void* state, const float* latents, int n, float* audio);
 
-/* mimi_encoder: audio[samples] at 24 kHz -> out[frames][d_model]; returns frames (rows written <= cap_frames)
- * or -1                                                             (src/pocket_tts.cpp:261-291). */
+/* mimi_encoder: audio[samples] at 24 kHz -> out[frames][d_model]; returns the frames the clip gives, or -1.  At most
+ * cap_frames rows are written: a return value above cap_frames (>= 0) means the output was cut there
+ *                                                                   (src/pocket_tts.cpp:261-291). */
 POCKET_TTS_API int ptts_mimi_encode(PocketTTSHandle handle, const float* audio, int samples, float* out, int cap_frames);
 /* The same over n_clips clips of `samples` samples each, stacked through the encoder together (the reference encodes one
- * clip per call, src/pocket_tts.cpp:241-297): outs[i] receives clip i's rows; returns the rows per clip. */
+ * clip per call, src/pocket_tts.cpp:241-297): outs[i] receives clip i's rows; returns the rows per clip (each outs[i] gets at
+ * most cap_frames of them, as above). */
 POCKET_TTS_API int ptts_mimi_encode_batch(PocketTTSHandle handle, const float* const* clips, int n_clips, int samples, float* const* outs,
                                           int cap_frames);
 

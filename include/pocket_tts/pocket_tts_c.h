@@ -11,7 +11,9 @@
  *     through pocket_tts_get_last_error() on the calling thread;
  *   - handles are plain heap objects owned by the caller until the matching destroy/free call;
  *   - calls block until the work is done; streaming callbacks run on the calling thread;
- *   - one handle may be used from several threads at once (calls are serialised per handle).
+ *   - one handle may be used from several threads at once: concurrent pocket_tts_generate and
+ *     pocket_tts_generate_streaming calls share the GPU (their utterances step side by side in one slot
+ *     table); pocket_tts_cancel_streaming ends the streams that are running when it is called.
  * There is no CPU fallback: creating a handle fails when no HIP device is present.
  */
 #ifndef POCKET_TTS_C_H

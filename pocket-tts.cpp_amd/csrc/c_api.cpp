@@ -472,7 +472,7 @@ POCKET_TTS_API int ptts_mimi_decode(PocketTTSHandle handle, void* state, const f
 }
 
 POCKET_TTS_API int ptts_mimi_encode(PocketTTSHandle handle, const float* audio, int samples, float* out, int cap_frames) {
-    if (!handle || !audio || !out || samples <= 0) { set_error("Invalid parameters"); return -1; }
+    if (!handle || !audio || !out || samples <= 0 || cap_frames < 0) { set_error("Invalid parameters"); return -1; }
     return guarded("mimi_encode: ", [&] {
         auto& e = tts_of(handle)->engine();
         auto emb = e.encode_voice(audio, samples);
@@ -484,7 +484,7 @@ POCKET_TTS_API int ptts_mimi_encode(PocketTTSHandle handle, const float* audio, 
 
 POCKET_TTS_API int ptts_mimi_encode_batch(PocketTTSHandle handle, const float* const* clips, int n_clips, int samples, float* const* outs,
                                           int cap_frames) {
-    if (!handle || !clips || !outs || n_clips <= 0 || samples <= 0) { set_error("Invalid parameters"); return -1; }
+    if (!handle || !clips || !outs || n_clips <= 0 || samples <= 0 || cap_frames < 0) { set_error("Invalid parameters"); return -1; }
     return guarded("mimi_encode_batch: ", [&] {
         auto& e = tts_of(handle)->engine();
         std::vector<const float*> ptrs(clips, clips + n_clips);

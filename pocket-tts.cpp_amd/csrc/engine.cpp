@@ -591,7 +591,7 @@ Batch::Batch(Engine& e, int B_, bool lm_only_) : B(B_), Bw(B_), lm_only(lm_only_
     PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_x0), static_cast<size_t>(3) * B * L * 4));   // BOS rows + two sets of start points
     PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_eos_all), static_cast<size_t>(std::max(o.max_frames, 16)) * B * 4, hipHostMallocMapped));
     PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_flag), 64, hipHostMallocMapped));
-    *h_flag = 0;
+    h_flag[0] = 0; h_flag[1] = 0;   // [0]: frames published; [1]: mirror of the persistent head's error word
     step_dev.alloc(64);
     partial.alloc(static_cast<size_t>(16) * B * D * 4);   // up to 16 K-slice slabs, sized once: the frame graph holds the pointer
     if (e.model().lm_wtype == W_I8 && D % 64 == 0 && s.lm_ffn % 64 == 0 && D == s.lm_heads * 64) {
@@ -823,7 +823,7 @@ Engine::Engine(const EngineOptions& opt) : opt_(opt) {
 
 Engine::~Engine() {
     PTTS_TRACE("dtor: begin");
-    struct Release { bool own; int dev; ~Release() { if (own) g_ring_owner[dev & 63].store(0); } } release{owns_ring_, opt_.device};
+    struct Release { bool own; int dev; ~Release() { if (own) g_ring_owner[dev & 63].store(0); } } release{owns_ring_ || ring_gave_up_, opt_.device};
     stop_worker();
     PTTS_TRACE("dtor: worker joined");
     (void)hipSetDevice(opt_.device);
@@ -1221,8 +1221,18 @@ void Engine::check_flow_ring(const unsigned* ctl, int rows) {
     sync_copy(&err, ctl + flow_ring_err_word(rows, spec().flow_blocks), 4, hipMemcpyDeviceToHost);
     if (err) {
         sync_fill(const_cast<unsigned*>(ctl), 0, 4);
-        throw std::runtime_error("flow head: a hand-off between workgroups timed out (the persistent launch was not fully resident)");
+        ring_failed();
+        throw std::runtime_error("flow head: a hand-off between workgroups timed out (the persistent launch was not fully resident); "
+                                 "this engine runs the head as a launch chain from now on");
     }
+}
+
+// After a failed hand-off the engine stops using the persistent head: every later call runs the launch chain.  The captured
+// frame graphs of pooled batches hold the persistent launch and are dropped (the streams are idle: the caller has drained them).
+void Engine::ring_failed() {
+    owns_ring_ = false;
+    ring_gave_up_ = true;
+    for (auto& kv : batch_pool_) kv.second->drop_graphs();
 }
 
 // frame (optional): the batch whose frame bookkeeping (EOS publication, frame counter, latent filing) rides in the launches
@@ -1250,6 +1260,10 @@ void Engine::flow_core(const FlowScratch& fs, hipStream_t st, const float* cond_
     probe.block_wtype = model_->flow_block_wtype; probe.ring_split = model_->flow_ring_split; probe.ring_ctl = fs.ctl; probe.ring_wg_budget = 224 / std::max(lanes_, 1);
     const bool ring = owns_ring_ && fs.ctl && flow_ring_supported(probe);
     const int cw = static_cast<int>(flow_ring_counter_word());
+    if (frame && ring) {   // h_flag[1] mirrors the head's error word (see FramePublish)
+        pub.ring_err = fs.ctl + flow_ring_err_word(B, s.flow_blocks);
+        pub.h_ring_err = reinterpret_cast<unsigned*>(frame->h_flag + 1);
+    }
     // the adaLN product: where its rows-stationary kernel applies (640 x 10240 x 512 at 64 rows), the kernel in front of it
     // leaves the rows as two-term bf16 fragments in the same buffer and the product loads them as they are
     // (POCKET_TTS_ADA_F32_ROWS=1: f32 rows, converted and reordered by the product)

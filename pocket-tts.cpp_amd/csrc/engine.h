@@ -261,6 +261,7 @@ private:
     void flow_scratch_layout(int rows, size_t off[6]) const;
     // After the stream has drained: throws if a hand-off wait of the persistent flow head gave up during the calls since the last check.
     void check_flow_ring(const unsigned* ctl, int rows);
+    void ring_failed();
     // slot0 / nb: the contiguous range of slots the chunk is decoded for (nb < 0: all).  ring_start >= 0: the latent rows come from
     // the batch's latent rings starting at that ring index instead of lat_dev.  due_mask: slots (bit = slot index) whose streaming state
     // the chunk advances; the others are computed along and left as they were.
@@ -291,6 +292,7 @@ private:
     std::mutex mu_;
     std::recursive_mutex call_mu_;
     std::mt19937 rng_;
+    std::mutex rng_mu_;        // rng_ is drawn from by queued calls, staged batches and in-line streams alike
     unsigned char* static_scratch_ = nullptr;   // this device's copy of the static scratch array (noalloc.cpp)
     void init_static_scratch();
     DevBuf flow_te_;  // [lsd_steps][C] averaged time embeddings of the fixed (s_j, t_j) grid
@@ -305,6 +307,7 @@ private:
     std::mutex enc_mu_;
     std::atomic<int> pending_{0};
     bool owns_ring_ = false;   // this engine holds its GPU's one persistent flow-head slot (see flow_ring.hip)
+    bool ring_gave_up_ = false;   // ... and stopped using it after a failed hand-off (the slot stays taken until the engine goes)
     std::map<std::pair<int, int>, std::unique_ptr<Batch>> batch_pool_;   // (rows, lane)
     std::list<std::pair<int, int>> batch_lru_;                           // keys of batch_pool_, most recently used first
     static constexpr size_t kMaxPooled = 8;                              // batch sizes kept warm per engine
@@ -327,6 +330,8 @@ private:
     // first p % of the delay it has seen on average before polling: measured at p = 60 on the 64 x 125 bf16 workload, the
     // process drops from 100 % to 37 % of a core and the frame from 0.85 ms to 1.10 ms (the wake-up is late), so it is off
     // by default.  Throws if the stream drains without the counter reaching `target`.
+    // A wall-clock limit applies (100 x the running average, at least POCKET_TTS_WAIT_LIMIT_MS, default 2000 ms): a frame that
+    // never publishes fails the call with a message instead of hanging it; a HIP error on the stream is thrown as it is.
     struct FlagWait { double avg_us = 0; };
     void wait_flag(const int* flag, int target, hipStream_t st, FlagWait& w);
     void submit(Request& r);

@@ -134,8 +134,11 @@ void Engine::stage_part(Batch& b, const Utterance* utts, int B) {
         if (b.noise_all.bytes < static_cast<size_t>(B) * per * 4) b.noise_all.alloc(static_cast<size_t>(B) * per * 4);
         std::vector<float> host(static_cast<size_t>(B) * per, 0.f);
         std::vector<uint32_t> seeds(static_cast<size_t>(B), 0u);
-        for (int i = 0; i < B; ++i)
-            if (!utts[i].noise && opt_.temperature > 0) seeds[i] = static_cast<uint32_t>(rng_());   // in utterance order
+        {
+            std::lock_guard<std::mutex> lk(rng_mu_);
+            for (int i = 0; i < B; ++i)
+                if (!utts[i].noise && opt_.temperature > 0) seeds[i] = static_cast<uint32_t>(rng_());   // in utterance order
+        }
         auto fill = [&](int i) {
             float* dst = host.data() + static_cast<size_t>(i) * per;
             if (utts[i].noise) {
@@ -302,7 +305,11 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
 
     size_t n_finished = 0;
     FlagWait flag_wait;
+    auto last_progress = std::chrono::steady_clock::now();   // several parts are polled in turn: none may stall for longer than the wait limit
+    static const double stall_ms = [] { const char* e = std::getenv("POCKET_TTS_WAIT_LIMIT_MS"); return static_cast<double>(e ? std::max(1, std::atoi(e)) : 2000); }();
     while (n_finished < runs.size()) {
+        if (runs.size() > 1 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - last_progress).count() > stall_ms)
+            throw std::runtime_error("no part of the staged batch published a frame within " + std::to_string(static_cast<long>(stall_ms)) + " ms");
         for (auto& r : runs) {
             if (r.finished || r.launched) continue;
             Batch& b = *r.b;
@@ -317,6 +324,7 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
             Batch& b = *r.b;
             if (__atomic_load_n(b.h_flag, __ATOMIC_ACQUIRE) < r.step + 1) { __builtin_ia32_pause(); continue; }   // EOS logits of this step not here yet
             const int B = b.B, step = r.step;
+            last_progress = std::chrono::steady_clock::now();
             r.executed = step + 1;
             if (timing_ && step > 0) { collect_timing(b, (step - 1) & 1); r.timed = step; }   // frame step-1 has fully retired
             const float* e_now = b.h_eos_all + static_cast<size_t>(step) * B;
@@ -425,7 +433,10 @@ int Engine::generate_streaming_inline(const Utterance& utt, int chunk_frames, co
     prefill_utterance(b, 0, utt);
     std::vector<Utterance> one{utt};
     std::vector<std::mt19937> rngs;
-    rngs.emplace_back(rng_());
+    {
+        std::lock_guard<std::mutex> lk(rng_mu_);
+        rngs.emplace_back(rng_());
+    }
     const bool any_noise = opt_.temperature > 0 || utt.noise;
     // Same frame body as the batched loop (one graph launch per frame): the EOS logit reaches mapped host memory from
     // inside the flow phase, the new latent is filed under its frame index, and nothing else leaves the device.
@@ -867,14 +878,22 @@ void Engine::op_mimi_decode(Batch* b, const float* latents, int n, float* audio)
 
 void Engine::wait_flag(const int* flag, int target, hipStream_t st, FlagWait& w) {
     static const int sleep_pct = [] { const char* e = std::getenv("POCKET_TTS_WAIT_SLEEP_PCT"); return e ? std::max(0, std::min(90, std::atoi(e))) : 0; }();
+    static const double floor_us = [] { const char* e = std::getenv("POCKET_TTS_WAIT_LIMIT_MS"); return 1e3 * (e ? std::max(1, std::atoi(e)) : 2000); }();
     const auto t0 = std::chrono::steady_clock::now();
     if (sleep_pct > 0 && w.avg_us > 150.0) std::this_thread::sleep_for(std::chrono::microseconds(static_cast<long>(w.avg_us * sleep_pct / 100.0)));
+    const double limit_us = std::max(floor_us, 100.0 * w.avg_us);
     for (unsigned spins = 1; __atomic_load_n(flag, __ATOMIC_ACQUIRE) < target; ++spins) {
         __builtin_ia32_pause();
         if ((spins & 0x3fff) == 0) {
-            const bool idle = hipStreamQuery(st) == hipSuccess;
-            if (!idle) (void)hipGetLastError();
-            if (idle && __atomic_load_n(flag, __ATOMIC_ACQUIRE) < target) throw std::runtime_error("frame finished without publishing its EOS logits");
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipErrorNotReady) (void)hipGetLastError();
+            else if (q != hipSuccess) PTTS_HIP(q);   // a real failure (launch error, lost device): not something to wait out
+            else if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < target) throw std::runtime_error("frame finished without publishing its EOS logits");
+            const double waited = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > limit_us)
+                throw std::runtime_error("frame " + std::to_string(target - 1) + " did not publish within " + std::to_string(static_cast<long>(waited / 1e3)) +
+                                         " ms (frames published: " + std::to_string(__atomic_load_n(flag, __ATOMIC_ACQUIRE)) + ", stream still busy, flow-head error word " +
+                                         std::to_string(static_cast<unsigned>(__atomic_load_n(flag + 1, __ATOMIC_ACQUIRE))) + ")");
         }
     }
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();

@@ -10,6 +10,7 @@
 #include <iostream>
 #include <map>
 #include <mutex>
+#include <set>
 #include <sstream>
 #include <thread>
 
@@ -30,7 +31,11 @@ struct PocketTTS::Impl {
     std::unique_ptr<Tokenizer> tokenizer;
     std::mutex cache_mu;
     std::map<std::string, std::vector<float>> voice_cache;  // keyed by path, like the reference (:75, :243-246)
-    std::atomic<bool> cancel_requested{false};
+    // One flag per running stream.  cancelStreaming() raises the flags of the streams that are running when it is called: a
+    // stream that starts afterwards is not affected and cannot un-cancel the others (the reference has one stream per handle
+    // and one flag that every stream start clears, src/pocket_tts.cpp:698, :981-983).
+    std::mutex cancel_mu;
+    std::set<std::atomic<bool>*> live_streams;
 
     explicit Impl(const PocketTTSConfig& cfg) : config(cfg) {
         ptts::EngineOptions o;
@@ -64,6 +69,21 @@ struct PocketTTS::Impl {
             if (const char* e = std::getenv("POCKET_TTS_ENGINES_PER_GPU"))
                 devices.assign(static_cast<size_t>(std::max(1, std::min(std::atoi(e), 3))), cfg.device);
         if (!devices.empty()) o.device = devices[0];
+        {
+            // Every engine's frame loop needs a hardware queue of its own (two streams on one queue run their work one after
+            // the other: measured 7550 -> 4180 RTFx with two engines), and the device's side stream takes one more.  A process
+            // gets GPU_MAX_HW_QUEUES of them per GPU (4 unless the variable says otherwise); CU-masked decoder streams do not count.
+            int hwq = 4, lanes = 1;
+            if (const char* e = std::getenv("GPU_MAX_HW_QUEUES")) hwq = std::max(1, std::atoi(e));
+            if (const char* e = std::getenv("POCKET_TTS_LANES")) lanes = std::max(1, std::min(std::atoi(e), 8));
+            std::map<int, int> per_dev;
+            for (int d : devices) per_dev[d] += lanes;
+            for (auto& kv : per_dev)
+                if (kv.second > 1 && kv.second + 1 > hwq)
+                    throw std::runtime_error("GPU " + std::to_string(kv.first) + ": " + std::to_string(kv.second) + " frame-loop streams and the side stream need " +
+                                             std::to_string(kv.second + 1) + " hardware queues, the process has " + std::to_string(hwq) +
+                                             " (GPU_MAX_HW_QUEUES); list fewer engines for that GPU");
+        }
         engine = std::make_unique<ptts::Engine>(o);
         for (size_t i = 1; i < devices.size(); ++i) {
             ptts::EngineOptions oi = o;
@@ -267,7 +287,12 @@ int PocketTTS::generateStreaming(const std::string& text, const std::vector<floa
                                  const std::vector<int64_t>& voiceEmbeddingShape, AudioChunkCallback callback,
                                  const StreamingConfig& streamConfig) {
     if (!callback) throw std::invalid_argument("Callback must be provided");
-    impl_->cancel_requested = false;  // :698
+    std::atomic<bool> my_cancel{false};   // starts clear, as the reference's flag does at every stream start (:698)
+    struct Registered {
+        Impl& im; std::atomic<bool>* f;
+        Registered(Impl& i, std::atomic<bool>* flag) : im(i), f(flag) { std::lock_guard<std::mutex> lk(im.cancel_mu); im.live_streams.insert(f); }
+        ~Registered() { std::lock_guard<std::mutex> lk(im.cancel_mu); im.live_streams.erase(f); }
+    } registered(*impl_, &my_cancel);
     ptts::Utterance u;
     u.token_ids = impl_->tokenize(text);
     u.voice = voiceEmbeddings.data();
@@ -276,7 +301,7 @@ int PocketTTS::generateStreaming(const std::string& text, const std::vector<floa
     std::function<void(int)> progress;
     if (streamConfig.onProgress) progress = [&](int frame) { streamConfig.onProgress(frame, 0); };
     auto t0 = std::chrono::high_resolution_clock::now();
-    int total = impl_->least_loaded().generate_streaming(u, streamConfig.chunkSizeFrames, callback, &impl_->cancel_requested,
+    int total = impl_->least_loaded().generate_streaming(u, streamConfig.chunkSizeFrames, callback, &my_cancel,
                                                   streamConfig.enableCancellation, progress, nullptr);
     if (impl_->config.verbose) {
         auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
@@ -286,6 +311,9 @@ int PocketTTS::generateStreaming(const std::string& text, const std::vector<floa
     return total;
 }
 
-void PocketTTS::cancelStreaming() { impl_->cancel_requested = true; }
+void PocketTTS::cancelStreaming() {
+    std::lock_guard<std::mutex> lk(impl_->cancel_mu);
+    for (std::atomic<bool>* f : impl_->live_streams) f->store(true);
+}
 
 }  // namespace pocket_tts

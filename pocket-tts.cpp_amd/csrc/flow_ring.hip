@@ -32,6 +32,7 @@
 // bits at bf16 MFMA speed; the float launch chain it replaces runs f32 MFMAs at a sixteenth of that rate.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <set>
@@ -655,6 +656,17 @@ static bool ring_io2(const FlowHeadArgs& a, bool split, bool q8) {
     return !split && !q8 && a.host_tabs && a.host_tabs->r_in_lo && a.host_tabs->r_out_lo;
 }
 
+// Workgroups of the persistent launch that can be resident at once on the current device: what the runtime says one CU holds
+// of the largest variant (512 registers per lane and up to 160 KB of LDS: one) times the CU count.  Queried once per device
+// by flow_ring_prepare(), outside any stream capture; 0 = not queried (no limit known).
+static std::atomic<int> g_ring_resident[64];
+
+static int ring_resident_limit() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return g_ring_resident[dev & 63].load();
+}
+
 bool flow_ring_supported(const FlowHeadArgs& a) {
     if (std::getenv("FLOW_HEAD_NO_RING")) return false;
     const int bw = a.block_wtype < 0 ? a.wtype : a.block_wtype;
@@ -667,6 +679,9 @@ bool flow_ring_supported(const FlowHeadArgs& a) {
     // the row groups a workgroup serves keep their x rows in LDS: many rows on few replicas may not fit (the launch chain runs then)
     int rpg = 4, replicas = 1;
     flow_ring_shape(a.B, a.blocks, a.ring_wg_budget, split, rpg, replicas);
+    // every workgroup spins on its producers: a grid that cannot be resident all at once never finishes a hand-off
+    const int limit = ring_resident_limit();
+    if (limit > 0 && replicas * a.blocks * G > limit) return false;
     return ring_smem(rpg, (a.B + rpg - 1) / rpg, replicas, split, bw == W_I8, ring_io2(a, split, bw == W_I8)) <= 160 * 1024;
 }
 
@@ -718,6 +733,17 @@ static void ring_lds_limit(const void* kernel) {
 }
 
 void flow_ring_prepare() {
+    {
+        int dev = 0, per_cu = 0;
+        (void)hipGetDevice(&dev);
+        hipDeviceProp_t prop;
+        ring_lds_limit((const void*)flow_ring_kernel<4, 4, false, false, true>);
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)flow_ring_kernel<4, 4, false, false, true>, kThreads, 158 * 1024) == hipSuccess && per_cu > 0)
+            g_ring_resident[dev & 63].store(per_cu * prop.multiProcessorCount);
+        else
+            (void)hipGetLastError();
+    }
     ring_lds_limit((const void*)flow_ring_kernel<4, 8, false, false>);
     ring_lds_limit((const void*)flow_ring_kernel<4, 4, false, false>);
     ring_lds_limit((const void*)flow_ring_kernel<4, 8, true, false>);
@@ -763,7 +789,9 @@ void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s) {
     const size_t smem = ring_smem(rpg, r.ngroups, replicas, split, q8, io2);
     if (smem > 160 * 1024) throw std::runtime_error("flow ring: LDS request too large");
     const int G = ring_slices(split);
-    const int grid = replicas * a.blocks * G;
+    int grid = replicas * a.blocks * G;
+    // test hook: leave the last workgroup out, so that its consumers wait, give up after the spin limit and raise the error word
+    if (const char* e = std::getenv("FLOW_RING_TEST_DROP_WG")) if (std::atoi(e) > 0 && grid > 1) grid -= 1;
     if (a.probe_a) (void)hipEventRecord(a.probe_a, s);
     if (split) hipLaunchKernelGGL((flow_ring_kernel<4, 8, true, false>), dim3(grid), dim3(kThreads), smem, s, r);
     else if (q8 && G == 8) hipLaunchKernelGGL((flow_ring_kernel<4, 8, false, true>), dim3(grid), dim3(kThreads), smem, s, r);

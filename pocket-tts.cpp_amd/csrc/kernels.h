@@ -306,6 +306,9 @@ struct FramePublish {
     const float* eos = nullptr; int* step = nullptr; float* h_eos_all = nullptr; int* h_flag = nullptr;
     int ring = 0;     // > 0: h_eos_all is a ring of this many steps (row = *step % ring)
     int stride = 0;   // > 0: floats per step row of h_eos_all (default: B)
+    // optional: a device word (the persistent flow head's error word, as the launches of earlier frames left it) copied to
+    // mapped host memory in front of the flag, so that the host sees a failed hand-off one frame after it happened
+    const unsigned* ring_err = nullptr; unsigned* h_ring_err = nullptr;
 };
 // zero / zero_words (optional): words the launch also sets to zero (the control words of a later kernel of the same frame)
 // frag: Y is written as the two bf16 terms of every value in MFMA fragment order instead of f32 rows (the same bytes in

@@ -525,6 +525,7 @@ __global__ void flow_mod_input_kernel(const float* te, const float* cemb, int sp
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) {
+            if (pub.h_ring_err) *pub.h_ring_err = *pub.ring_err;
             __hip_atomic_store(pub.h_flag, st + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             *pub.step = st + 1;
         }

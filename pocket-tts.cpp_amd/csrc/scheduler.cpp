@@ -36,6 +36,10 @@ constexpr int kDecChunk = 15;            // src/pocket_tts.cpp:461
 constexpr float kEosThreshold = -4.0f;   // src/pocket_tts.cpp:596
 constexpr int kSlabs = 8;                // pinned PCM slabs in flight
 constexpr int kWidths[] = {1, 2, 4, 8, 16, 32, 48, 64};   // launch widths of the frame body (occupied prefix, rounded up)
+
+// A hand-off of the persistent flow head gave up during the last frame steps: the utterances in the table have stale
+// latents and fail; utterances still queued did nothing wrong and are served by the next activation (launch chain).
+struct RingTimeout : std::runtime_error { using std::runtime_error::runtime_error; };
 }  // namespace
 
 struct Engine::Request {
@@ -52,6 +56,7 @@ struct Engine::Request {
     // set), counted down by the delivery thread; whoever brings it to zero on a closed request finishes the request
     std::atomic<int> outstanding{0};
     std::atomic<bool> closed{false};     // no further decode will be issued
+    std::atomic<bool> abandon{false};    // the caller's callback threw: stop at the next step, deliver nothing more
     std::vector<float> chunk_acc;        // streaming: sub-chunks of one callback's audio (delivery thread only)
     // ---- shared with the caller (mu)
     struct Event { int kind = 0; std::vector<float> samples; bool is_final = false; int frame = 0; };   // kind 0: chunk, 1: progress
@@ -107,6 +112,7 @@ struct Engine::Table {
     size_t due_pushed = 0;
     std::thread d_thread;
     int fs = 0, R = 0, L = 0, F = 0, device = 0;
+    double wait_limit_ms = 20000.0;      // ten times the frame wait's floor (POCKET_TTS_WAIT_LIMIT_MS)
 
     void deliver_main();
     static void finish(Request* r, std::exception_ptr err = nullptr) {
@@ -150,8 +156,17 @@ void Engine::Table::deliver_main() {
             ++in_flight;
         }
         std::exception_ptr err;
-        const hipError_t e = hipEventSynchronize(d.ev);
-        if (e != hipSuccess) err = std::make_exception_ptr(std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " while waiting for a decoder chunk"));
+        // bounded wait: a decoder chunk takes milliseconds; one that has not landed after wait_limit_ms fails its owners
+        hipError_t e = hipEventQuery(d.ev);
+        for (auto t0 = std::chrono::steady_clock::now(); e == hipErrorNotReady; e = hipEventQuery(d.ev)) {
+            (void)hipGetLastError();
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > wait_limit_ms) break;
+            if (ms > 0.2) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            else __builtin_ia32_pause();
+        }
+        if (e == hipErrorNotReady) err = std::make_exception_ptr(std::runtime_error("a decoder chunk did not finish within " + std::to_string(static_cast<long>(wait_limit_ms)) + " ms"));
+        else if (e != hipSuccess) err = std::make_exception_ptr(std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " while waiting for a decoder chunk"));
         PTTS_TRACEF("delivery: %d frames, %d items", d.n, static_cast<int>(d.items.size()));
         for (auto& it : d.items) {
             Request* r = it.req;
@@ -236,7 +251,7 @@ void Engine::submit_all(Request* const* reqs, size_t n) {
         std::vector<Request*> need;
         std::vector<uint32_t> seeds;
         if (opt_.temperature > 0) {
-            std::lock_guard<std::mutex> lk(q_mu_);
+            std::lock_guard<std::mutex> lk(rng_mu_);
             for (size_t i = 0; i < count; ++i)
                 if (!reqs[first + i]->utt.noise) { need.push_back(reqs[first + i]); seeds.push_back(static_cast<uint32_t>(rng_())); }   // seeds in request order
         }
@@ -330,6 +345,10 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
     submit(r);
     int total = 0;
     bool stopped = false;
+    // r and `local` live on this stack frame while the stepping and delivery threads hold pointers to them: nothing may
+    // unwind out of this loop before r.done.  A callback that throws abandons the stream (the worker stops it at its next
+    // step), the remaining events are drained and dropped, and the exception is rethrown afterwards.
+    std::exception_ptr user_err;
     for (;;) {
         Request::Event ev;
         {
@@ -339,17 +358,24 @@ int Engine::generate_streaming(const Utterance& utt, int chunk_frames, const Chu
             ev = std::move(r.events.front());
             r.events.pop_front();
         }
-        if (ev.kind == 1) {
-            if (!stopped && progress) progress(ev.frame);                                  // :891-893
-            continue;
+        if (user_err) continue;
+        try {
+            if (ev.kind == 1) {
+                if (!stopped && progress) progress(ev.frame);                                  // :891-893
+                continue;
+            }
+            // a cancel request ends the stream at the next frame when polling is on (:745-750) and always drops the tail flush (:897)
+            const bool cancelled = cancel_flag && cancel_flag->load();
+            if (stopped || (cancelled && (poll_cancel || ev.is_final))) { stopped = true; continue; }
+            if (capture) capture->audio.insert(capture->audio.end(), ev.samples.begin(), ev.samples.end());
+            cb(ev.samples.data(), static_cast<int>(ev.samples.size()), ev.is_final);
+            total += static_cast<int>(ev.samples.size());
+        } catch (...) {
+            user_err = std::current_exception();
+            r.abandon.store(true);
         }
-        // a cancel request ends the stream at the next frame when polling is on (:745-750) and always drops the tail flush (:897)
-        const bool cancelled = cancel_flag && cancel_flag->load();
-        if (stopped || (cancelled && (poll_cancel || ev.is_final))) { stopped = true; continue; }
-        if (capture) capture->audio.insert(capture->audio.end(), ev.samples.begin(), ev.samples.end());
-        cb(ev.samples.data(), static_cast<int>(ev.samples.size()), ev.is_final);
-        total += static_cast<int>(ev.samples.size());
     }
+    if (user_err) std::rethrow_exception(user_err);
     if (r.err) std::rethrow_exception(r.err);
     return total;
 }
@@ -387,8 +413,10 @@ void Engine::worker_main() {
             PTTS_TRACE("worker: activation failed");
             // a failure of the table itself (a HIP error): everyone waiting learns of it
             const std::exception_ptr err = std::current_exception();
+            bool keep_queue = false;
+            try { std::rethrow_exception(err); } catch (const RingTimeout&) { keep_queue = true; } catch (...) {}
             std::vector<Request*> victims;
-            {
+            if (!keep_queue) {
                 std::lock_guard<std::mutex> lk(q_mu_);
                 victims.assign(queue_.begin(), queue_.end());
                 queue_.clear();
@@ -435,6 +463,7 @@ void Engine::run_table() {
         N.b = std::make_unique<Batch>(*this, kSlots);
         N.pb = std::make_unique<Batch>(*this, kSlots, true);
         N.fs = fs; N.R = N.b->lat_frames; N.L = L; N.F = opt_.max_frames; N.device = opt_.device;
+        if (const char* e = std::getenv("POCKET_TTS_WAIT_LIMIT_MS")) N.wait_limit_ms = 10.0 * std::max(1, std::atoi(e));
         for (auto& p : N.slabs) PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), static_cast<size_t>(kSlots) * kDecChunk * fs * 4));
         for (auto& p : N.lat_slabs) PTTS_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), static_cast<size_t>(kSlots) * kDecChunk * L * 4));
         for (auto& e : N.dec_mark) PTTS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -714,9 +743,21 @@ void Engine::run_table() {
         // ---- the EOS logits of this step (the flow head of the step is still running when they arrive)
         wait_flag(b.h_flag, gs + 1, st, flag_wait);
         gpu.lock();
+        if (__atomic_load_n(b.h_flag + 1, __ATOMIC_ACQUIRE) != 0) {
+            // the persistent flow head of an earlier step gave up on a hand-off: every slot's latents since then are stale
+            PTTS_HIP(hipStreamSynchronize(st));
+            sync_fill(b.flow_ctl.p, 0, 4);
+            b.h_flag[1] = 0;
+            ring_failed();
+            throw RingTimeout("flow head: a hand-off between workgroups timed out at table step " + std::to_string(gs) +
+                              " (the persistent launch was not fully resident); the utterances in the table fail, later ones run the head as a launch chain");
+        }
         const float* e_now = b.h_eos_all + static_cast<size_t>(gs % b.eos_ring) * b.B;
         struct Due { Request* req; int slot, n, f0, gstart; bool last_sub, is_final, closes; };
         std::vector<Due> due;
+        // T.due_reqs follows `due` from the first append on (it is empty here), so that a failure anywhere below finds every
+        // request whose slot has already been cleared; it is put into issue order once `due` is sorted
+        auto add_due = [&](const Due& d) { due.push_back(d); T.due_reqs.push_back(d.req); };
         long frames_now = 0;
         for (int i = 0; i < width; ++i) {
             Table::Slot& S = T.slots[i];
@@ -729,6 +770,7 @@ void Engine::run_table() {
             if (e > kEosThreshold && S.eos_step < 0) S.eos_step = k;                           // :596
             if (S.eos_step >= 0 && k >= S.eos_step + opt_.frames_after_eos) stop = true;       // :601 (this step's flow output is not used)
             if (!stop && r->streaming && r->poll_cancel && r->cancel && r->cancel->load()) { stop = true; cancelled = true; }   // :745-750
+            if (!stop && r->abandon.load()) { stop = true; cancelled = true; }
             if (!stop) {
                 S.frames = k + 1;
                 ++frames_now;
@@ -752,18 +794,18 @@ void Engine::run_table() {
                     const bool tail = pending < r->chunk_frames;
                     for (int f0 = 0; f0 < pending; f0 += kDecChunk) {                          // sub-chunks of <= 15 frames (:796)
                         const int n = std::min(kDecChunk, pending - f0);
-                        due.push_back({r, i, n, S.decoded + f0, S.g0 + S.decoded + f0, f0 + n == pending, tail, false});
+                        add_due({r, i, n, S.decoded + f0, S.g0 + S.decoded + f0, f0 + n == pending, tail, false});
                     }
                     S.decoded = S.frames;
                 }
             } else if (pending > 0 && (stop || pending == kDecChunk)) {
-                due.push_back({r, i, pending, S.decoded, S.g0 + S.decoded, true, false, false});
+                add_due({r, i, pending, S.decoded, S.g0 + S.decoded, true, false, false});
                 S.decoded = S.frames;
             }
             if (stop) {
                 r->out->frames = S.frames;
                 // nothing left to decode: the request closes through an item without audio (ordered behind its earlier chunks)
-                if (due.size() == first_due) due.push_back({r, i, 0, S.frames, gs + 1, true, false, false});
+                if (due.size() == first_due) add_due({r, i, 0, S.frames, gs + 1, true, false, false});
                 due.back().closes = true;
                 // every item of the request is counted before it is marked closed: the delivery thread finishes a closed
                 // request when the count reaches zero

@@ -337,3 +337,63 @@ def test_latents_of_chunks_that_run_over_the_end_of_the_ring(packs, oracle_mod):
         assert snr_db(oracle_decode(o, res[i]["latents"]), res[i]["audio"]) >= 40.0, i
     assert st["frame_steps"] == 4 * F, st   # no step of the clock was spent waiting for a chunk boundary
     eng.close()
+
+
+@one_engine
+def test_flow_head_hand_off_that_gives_up_fails_the_table_and_not_the_queue(full_pack, oracle_mod, monkeypatch):
+    """The persistent flow head launched one workgroup short (FLOW_RING_TEST_DROP_WG): the consumers of the missing producer
+    spin to their limit and raise the error word, the launch drains, and the host sees the word with the next frame's EOS
+    logits.  The call must come back with an error well inside the wait limit (no hang, no audio made from stale latents);
+    the engine then runs the head as a launch chain, so the next call on the same handle succeeds and matches the oracle."""
+    import time
+    import ptts_lib as ptts
+    path, spec = full_pack
+    monkeypatch.setenv("FLOW_RING_TEST_DROP_WG", "1")
+    F = 6
+    eng = ptts.Engine(path, precision="bf16", temperature=0.0, lsd_steps=10, max_frames=F)
+    rng = np.random.default_rng(21)
+    ids, voices = _ragged(spec, rng, 3, tmax=12, vmax=20)
+    t0 = time.perf_counter()
+    with pytest.raises(ptts.PttsError, match="hand-off between workgroups timed out"):
+        eng.generate_ids(ids, voices, queued=True)
+    took = time.perf_counter() - t0
+    assert took < 30.0, took
+    monkeypatch.delenv("FLOW_RING_TEST_DROP_WG")
+    res = eng.generate_ids(ids, voices, queued=True)     # launch chain from here on
+    import ptts_pack as pp
+    d = os.path.join(os.path.dirname(path), "full_bf16w_giveup.ptts")
+    pp.write_pack(d, spec, pp.bf16_model(pp.read_pack(path)[1]))
+    o = oracle_mod.Oracle(d)
+    worst = 0.0
+    for i in range(3):
+        assert res[i]["frames"] == F and np.isfinite(res[i]["audio"]).all()
+        lat, eos, frames = oracle_replay(o, ids[i], voices[i], res[i]["latents"], 10, F)
+        worst = max(worst, float(np.abs(lat - res[i]["latents"]).max()))
+    _note(f"flow-head give-up: error returned after {took:.2f} s; the same handle on the launch chain afterwards: latent max-abs {worst:.3e}")
+    assert worst <= 2e-2
+    eng.close()
+
+
+def test_streaming_hazards_from_a_cpp_caller(full_pack, tmp_path):
+    """tests/cpp/stream_hazards.cpp against the library: a chunk callback that throws (the exception reaches the caller, the
+    handle serves the next stream), and cancelStreaming() with four streams running followed at once by a fifth (the four
+    end early, the fifth completes)."""
+    import shutil
+    import subprocess
+    import ptts_lib as ptts
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "stream_hazards")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/stream_hazards not built (make -C oracle own_tests)")
+    path, spec = full_pack
+    models = tmp_path / "models"
+    models.mkdir()
+    os.symlink(path, models / "pocket_tts.ptts")
+    tok = os.path.join(root, "tests", "golden", "sp_unigram.model")
+    t = np.arange(2 * 24000) / 24000.0
+    ptts.audio_save_wav(str(tmp_path / "voice.wav"), (0.3 * np.sin(2 * np.pi * 200.0 * t)).astype(np.float32), 24000)
+    pkg = os.path.join(root, "pocket-tts.cpp_amd")
+    env = dict(os.environ, LD_LIBRARY_PATH=pkg + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, str(models), tok, str(tmp_path / "voice.wav")], env=env, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    _note("stream_hazards: " + " | ".join(r.stdout.strip().splitlines()[:-1]))
