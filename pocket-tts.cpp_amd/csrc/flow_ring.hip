@@ -32,6 +32,7 @@
 // bits at bf16 MFMA speed; the float launch chain it replaces runs f32 MFMAs at a sixteenth of that rate.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
@@ -79,6 +80,25 @@ __device__ __forceinline__ float wsum(float v) {
     const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
     return (r0 + r1) + (r2 + r3);
+}
+
+// Mean and (biased) variance of one 512-wide row held as two float4 pieces per lane.  ONEPASS: the sums of x and of x * x
+// are reduced side by side (two independent reductions whose latencies overlap) and var = E[x^2] - mean^2; otherwise the
+// deviations are formed first, as the launch chain and the int8 form do (the int8 form must round as its oracle does).
+template <bool ONEPASS>
+__device__ __forceinline__ void row_moments(const float4 h0, const float4 h1, float& mean, float& var) {
+    const float s1 = ((h0.x + h0.y) + (h0.z + h0.w)) + ((h1.x + h1.y) + (h1.z + h1.w));
+    if constexpr (ONEPASS) {
+        const float s2 = ((h0.x * h0.x + h0.y * h0.y) + (h0.z * h0.z + h0.w * h0.w)) + ((h1.x * h1.x + h1.y * h1.y) + (h1.z * h1.z + h1.w * h1.w));
+        const float a1 = wsum(s1), a2 = wsum(s2);
+        mean = a1 * (1.0f / (float)C);
+        var = fmaxf(a2 * (1.0f / (float)C) - mean * mean, 0.f);
+    } else {
+        mean = wsum(s1) * (1.0f / (float)C);
+        const float d0 = h0.x - mean, d1 = h0.y - mean, d2 = h0.z - mean, d3 = h0.w - mean;
+        const float d4 = h1.x - mean, d5 = h1.y - mean, d6 = h1.z - mean, d7 = h1.w - mean;
+        var = wsum(((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7))) * (1.0f / (float)C);
+    }
 }
 
 // A-operand fragment of k-step k0 / 32: only the first RPG rows of a plane are live, MFMA row r reads row r % RPG (lanes
@@ -194,6 +214,11 @@ struct FlowRingArgs {
 template <int RPG, int G, bool WS, bool Q8, bool IO2 = false>
 __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
     constexpr bool WIO = WS || IO2;
+#ifdef PTTS_RING_TWO_PASS_LN
+    constexpr bool ONEPASS = false;
+#else
+    constexpr bool ONEPASS = !Q8;
+#endif
     static_assert(!(WS && IO2) && !(Q8 && IO2), "flow ring: IO2 is the bf16 form with two-term projections");
     constexpr int NT1 = NT / G, NW1 = NT1 / kWaves, KS2 = KS / G, CS = C / G, LDA2 = lda2_of(G);
     constexpr int KS2Q = KSQ / G, LDSQ = CS + 16;
@@ -345,10 +370,11 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
             }
             h0.x += gt0.x * (s0.x + pb0.x); h0.y += gt0.y * (s0.y + pb0.y); h0.z += gt0.z * (s0.z + pb0.z); h0.w += gt0.w * (s0.w + pb0.w);
             h1.x += gt1.x * (s1.x + pb1.x); h1.y += gt1.y * (s1.y + pb1.y); h1.z += gt1.z * (s1.z + pb1.z); h1.w += gt1.w * (s1.w + pb1.w);
-            const float mean = wsum(((h0.x + h0.y) + (h0.z + h0.w)) + ((h1.x + h1.y) + (h1.z + h1.w))) * (1.0f / (float)C);
+            float mean, var;
+            row_moments<ONEPASS>(h0, h1, mean, var);
             const float d0 = h0.x - mean, d1 = h0.y - mean, d2 = h0.z - mean, d3 = h0.w - mean;
             const float d4 = h1.x - mean, d5 = h1.y - mean, d6 = h1.z - mean, d7 = h1.w - mean;
-            const float rstd = __builtin_amdgcn_rsqf(wsum(((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7))) * (1.0f / (float)C) + a.eps);
+            const float rstd = __builtin_amdgcn_rsqf(var + a.eps);
             float4 y0, y1;
             y0.x = (d0 * rstd) * (1.0f + sc0.x) + sh0.x; y0.y = (d1 * rstd) * (1.0f + sc0.y) + sh0.y;
             y0.z = (d2 * rstd) * (1.0f + sc0.z) + sh0.z; y0.w = (d3 * rstd) * (1.0f + sc0.w) + sh0.w;
@@ -475,10 +501,11 @@ __global__ __launch_bounds__(kThreads) void flow_ring_kernel(FlowRingArgs a) {
                     st_sc1(rs, h_off_mine + ro + c0 * 4, h0);
                     st_sc1(rs, h_off_mine + ro + c1 * 4, h1);
                 }
-                const float mean = wsum(((h0.x + h0.y) + (h0.z + h0.w)) + ((h1.x + h1.y) + (h1.z + h1.w))) * (1.0f / (float)C);
+                float mean, var0;
+                row_moments<ONEPASS>(h0, h1, mean, var0);
                 const float d0 = h0.x - mean, d1 = h0.y - mean, d2 = h0.z - mean, d3 = h0.w - mean;
                 const float d4 = h1.x - mean, d5 = h1.y - mean, d6 = h1.z - mean, d7 = h1.w - mean;
-                const float var = wsum(((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7))) * (1.0f / (float)C) + a.eps;
+                const float var = var0 + a.eps;
                 const float rstd = Q8 ? 1.0f / sqrtf(var) : __builtin_amdgcn_rsqf(var);
                 float4 y0, y1;
                 y0.x = (d0 * rstd * lg0.x + lb0.x) * (1.0f + sc0.x) + sh0.x; y0.y = (d1 * rstd * lg0.y + lb0.y) * (1.0f + sc0.y) + sh0.y;
@@ -786,7 +813,8 @@ void launch_flow_ring(const FlowHeadArgs& a, hipStream_t s) {
     r.ctl = a.ring_ctl;
     r.eps = a.eps; r.dt = 1.0f / (float)a.steps;
     r.stamps = a.cycle_probe;
-    const size_t smem = ring_smem(rpg, r.ngroups, replicas, split, q8, io2);
+    size_t smem = ring_smem(rpg, r.ngroups, replicas, split, q8, io2);
+    if (const char* e = std::getenv("FLOW_RING_LDS_PAD")) smem = std::min<size_t>(smem + (size_t)std::atoi(e), 160 * 1024);   // experiment: what the LDS size alone costs
     if (smem > 160 * 1024) throw std::runtime_error("flow ring: LDS request too large");
     const int G = ring_slices(split);
     int grid = replicas * a.blocks * G;

@@ -243,6 +243,7 @@ static void bench_flow(int B) {
     a.w_in = packed_weight(C, L, W_T); a.b_in = (const float*)dalloc(C * 4);
     a.w_out = packed_weight(L, C, W_T); a.b_out = (const float*)dalloc(L * 4);
     if (W_T == W_BF16) { tabs.r_fc1 = tabs.w_fc1; tabs.r_fc2 = tabs.w_fc2; tabs.r_in = a.w_in; tabs.r_out = a.w_out; }   // the persistent form's planes
+    if (W_T == W_BF16 && !q8 && std::getenv("KB_FLOW_IO2")) { tabs.r_in_lo = a.w_in; tabs.r_out_lo = a.w_out; }   // timing only: second planes = copies of the first
     a.host_tabs = &tabs; a.workspace = (float*)dalloc(flow_head_workspace_bytes(B, C, W_T, nb), 0); a.wtype = W_T;
     if (q8) a.block_wtype = W_I8;
     flow_head_prepare(C, W_T);
