@@ -167,6 +167,12 @@ POCKET_TTS_API int ptts_q8_linear(PocketTTSHandle handle, const float* A, int M,
 POCKET_TTS_API int ptts_q8_linear_q(PocketTTSHandle handle, const float* A, int M, int K, const signed char* q, const float* scale, int N,
                                     float* out);
 
+/* The same product in the int8 engine's second activation scheme, the one ONNX Runtime's dynamically quantised graphs
+ * use (DynamicQuantizeLinear + MatMulInteger; the reference's *_int8.onnx models, src/pocket_tts.cpp:232-246): each row
+ * of A becomes uint8 with one scale and one zero point over the whole row (range widened to include 0), W is int8 per
+ * output row, the integer sum runs over all of K and is scaled once. */
+POCKET_TTS_API int ptts_q8_linear_dyn(PocketTTSHandle handle, const float* A, int M, int K, const float* W, int N, float* out);
+
 /* The bf16-weight matrix product on its own: out[M][N] = act(A . W^T + bias) * colscale + R (bias, colscale, R may be
  * NULL; act: 0 none, 1 GELU, 2 SiLU, 3 ELU; W is rounded to bf16).  flags bit 0: carry A as two bf16 terms; bit 1: keep
  * the A rows in bf16 in device memory; bit 2: keep the C rows in bf16.  For checking the kernels at arbitrary shapes; the

@@ -35,6 +35,7 @@ def lib() -> C.CDLL:
         L.ptts_oracle_load.argtypes = [C.c_char_p]
         L.ptts_oracle_free.argtypes = [C.c_void_p]
         L.ptts_oracle_enable_q8.argtypes = [C.c_void_p]
+        L.ptts_oracle_q8_linear.argtypes = [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int, f32p]
         L.ptts_oracle_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.ptts_oracle_text_conditioner.argtypes = [C.c_void_p, i64p, C.c_int, f32p]
         L.ptts_oracle_lm_state_new.restype = C.c_void_p
@@ -60,6 +61,16 @@ def lib() -> C.CDLL:
     return _LIB
 
 
+def q8_linear(A, W, scheme: int = 0) -> np.ndarray:
+    """A . W^T with W int8 per output row and A quantised per the scheme (0: per row and block of 64, symmetric;
+    1: ONNX DynamicQuantizeLinear per row, uint8 with a zero point), as ptts_oracle.c's linear_q8 does inside the model."""
+    A = np.ascontiguousarray(A, np.float32)
+    W = np.ascontiguousarray(W, np.float32)
+    out = np.empty((A.shape[0], W.shape[0]), np.float32)
+    lib().ptts_oracle_q8_linear(A, A.shape[0], A.shape[1], W, W.shape[0], scheme, out)
+    return out
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -72,7 +83,8 @@ class Oracle:
         self.h = self.L.ptts_oracle_load(pack_path.encode())
         if not self.h:
             raise RuntimeError(f"oracle: cannot load pack {pack_path}")
-        if int8:   # LM-layer and flow-block matrices in the engine's int8 scheme (see ptts_oracle.c, linear_q8)
+        if int8:   # LM-layer and flow-block matrices in the engine's int8 scheme (see ptts_oracle.c, linear_q8); the
+            # activation scheme is the pack's (Spec.q8_act_scheme)
             self.L.ptts_oracle_enable_q8(self.h)
         d = (C.c_int * 6)()
         self.L.ptts_oracle_dims(self.h, d)

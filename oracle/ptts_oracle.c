@@ -47,7 +47,7 @@ typedef struct {
     int latent, d_model, lm_layers, lm_heads, lm_ffn, lm_max_period, vocab;
     int flow_dim, flow_blocks, flow_freq;
     int mimi_dim, mimi_layers, mimi_heads, mimi_ffn, mimi_context, mimi_max_period;
-    int n_filters, ratios[3], kernel, last_kernel, res_kernel, upsample, sample_rate;
+    int n_filters, ratios[3], kernel, last_kernel, res_kernel, upsample, sample_rate, q8_act_scheme;
     float lm_eps, flow_eps, mimi_eps, flow_max_period;
     int frame_size;
 } Spec;
@@ -104,6 +104,7 @@ Oracle *ptts_oracle_load(const char *path) {
     s->mimi_context = iv[14]; s->mimi_max_period = iv[15]; s->n_filters = iv[16];
     s->ratios[0] = iv[17]; s->ratios[1] = iv[18]; s->ratios[2] = iv[19];
     s->kernel = iv[20]; s->last_kernel = iv[21]; s->res_kernel = iv[22]; s->upsample = iv[23]; s->sample_rate = iv[24];
+    s->q8_act_scheme = iv[25];
     s->lm_eps = fv[0]; s->flow_eps = fv[1]; s->mimi_eps = fv[2]; s->flow_max_period = fv[3];
     s->frame_size = s->upsample * s->ratios[0] * s->ratios[1] * s->ratios[2];
     return o;
@@ -144,8 +145,20 @@ void ptts_oracle_enable_q8_some(Oracle *o, int mask) {
     }
 }
 
-/* ... all of them: the int8 engine's scheme. */
-void ptts_oracle_enable_q8(Oracle *o) { ptts_oracle_enable_q8_some(o, 63); }
+/* Activation scheme the next registered int8 matrices get (each registry entry keeps its own, so oracles of both schemes
+ * can be alive at once): 0 = per row and block of 64, symmetric (the default); 1 = ONNX DynamicQuantizeLinear per row,
+ * uint8 with a zero point (see linear_q8_dyn). */
+static int g_q8_act = 0;
+void ptts_oracle_set_q8_act(int scheme) { g_q8_act = scheme; }
+
+/* ... all of them: the int8 engine's scheme.  In the dynamic uint8 scheme the flow blocks keep their bf16 matrices (the
+ * engine's persistent flow head quantises per block of 64 only), and the scheme is taken from the pack header. */
+void ptts_oracle_enable_q8(Oracle *o) {
+    const int saved = g_q8_act;
+    g_q8_act = o->s.q8_act_scheme;
+    ptts_oracle_enable_q8_some(o, g_q8_act == 1 ? 15 : 63);
+    g_q8_act = saved;
+}
 
 /* Attribution knob (tools/int8_attribution.py): which side of an int8 product is quantised.  3 = both (the engine's
  * scheme, the default), 1 = weights only (activations stay float32), 2 = activations only (weights stay float32). */
@@ -175,7 +188,7 @@ static float dotf(const float *a, const float *b, int n) {
  *   product      y[n] = (sum over blocks of (float)(sum_k qx*qw) * d) * sw[n] + bias[n], blocks in k order
  * Applied to the LM layers' qkv/out/ff1/ff2 and (when flow_dim is a multiple of 256) the flow head's fc1/fc2
  * matrices; every other matrix keeps its bf16-rounded weights.  A quantised matrix is recognised by its address in the weight blob. */
-typedef struct { const float *W; int N, K; int8_t *q; float *sw; } Q8Entry;
+typedef struct { const float *W; int N, K, act; int8_t *q; float *sw; } Q8Entry;
 static Q8Entry g_q8[128];
 static int g_nq8 = 0;
 
@@ -188,7 +201,7 @@ static const Q8Entry *q8_find(const float *W) {
 static void q8_register(const float *W, int N, int K) {
     if (q8_find(W) || g_nq8 >= 128 || K % 64) return;
     Q8Entry *e = &g_q8[g_nq8];
-    e->W = W; e->N = N; e->K = K;
+    e->W = W; e->N = N; e->K = K; e->act = g_q8_act;
     e->q = (int8_t *)malloc((size_t)N * K);
     e->sw = (float *)malloc((size_t)N * sizeof(float));
     for (int n = 0; n < N; ++n) {
@@ -219,8 +232,57 @@ static void q8_forget(const unsigned char *lo, const unsigned char *hi) {
 
 static float dotf(const float *a, const float *b, int n);
 
+/* ONNX DynamicQuantizeLinear + MatMulInteger, the activation scheme of a dynamically quantised ONNX graph (the
+ * reference's *_int8.onnx files, /root/reference/src/pocket_tts.cpp:90-96; operator definitions: ONNX opset 11).  The
+ * reference runs one utterance per call, so a decode step's activation tensor is one row; the rows of a longer pass are
+ * quantised one by one here as in the engine (ONNX Runtime would use one scale for the whole [T][K] tensor of a prefill call).
+ *   lo = min(0, min x), hi = max(0, max x), s = (hi - lo) / 255, zp = rint(clamp(-lo / s, 0, 255))
+ *   q = clamp(rint(x / s) + zp, 0, 255)                         (rint: half to even; s = 0: q = zp = 0)
+ *   y[n] = (float)(sum_k (q[k] - zp) * qw[n][k]) * (s * sw[n]) + bias[n]          (integer sum exact in int32)          */
+static void linear_q8_dyn(float *Y, int ldy, const float *X, int ldx, const Q8Entry *e, const float *bias, int M) {
+    const int N = e->N, K = e->K;
+#pragma omp parallel for schedule(static) if ((long)M * N * K > 400000)
+    for (int m = 0; m < M; ++m) {
+        const float *x = X + (long)m * ldx;
+        int *q = (int *)malloc((size_t)K * sizeof(int));
+        float lo = 0.f, hi = 0.f;
+        for (int k = 0; k < K; ++k) { if (x[k] < lo) lo = x[k]; if (x[k] > hi) hi = x[k]; }
+        float s = (hi - lo) / 255.0f;
+        int zp = 0;
+        if (s > 0.f) {
+            float z = -lo / s;
+            if (z < 0.f) z = 0.f;
+            if (z > 255.f) z = 255.f;
+            zp = (int)rintf(z);
+            for (int k = 0; k < K; ++k) {
+                int v = (int)rintf(x[k] / s) + zp;
+                q[k] = v < 0 ? 0 : (v > 255 ? 255 : v);
+            }
+        } else {
+            s = 0.f;
+            for (int k = 0; k < K; ++k) q[k] = 0;
+        }
+        if (g_q8_parts == 2) {   /* activations only: the de-quantised row against the float weights */
+            float *xd = (float *)malloc((size_t)K * sizeof(float));
+            for (int k = 0; k < K; ++k) xd[k] = (float)(q[k] - zp) * s;
+            for (int n = 0; n < N; ++n) Y[(long)m * ldy + n] = dotf(xd, e->W + (size_t)n * K, K) + (bias ? bias[n] : 0.f);
+            free(xd);
+            free(q);
+            continue;
+        }
+        for (int n = 0; n < N; ++n) {
+            const int8_t *qw = e->q + (size_t)n * K;
+            int isum = 0;
+            for (int k = 0; k < K; ++k) isum += (q[k] - zp) * (int)qw[k];
+            Y[(long)m * ldy + n] = (float)isum * (s * e->sw[n]) + (bias ? bias[n] : 0.f);
+        }
+        free(q);
+    }
+}
+
 static void linear_q8(float *Y, int ldy, const float *X, int ldx, const Q8Entry *e, const float *bias, int M) {
     const int N = e->N, K = e->K, KB = K / 64;
+    if (e->act == 1 && g_q8_parts != 1) { linear_q8_dyn(Y, ldy, X, ldx, e, bias, M); return; }
     if (g_q8_parts == 1) {   /* weights only: the float dot product with the de-quantised row */
 #pragma omp parallel for schedule(static) if ((long)M * N * K > 400000)
         for (int n = 0; n < N; ++n) {
@@ -313,6 +375,19 @@ static void rope(float *v, int dh, long pos, int max_period) {
         v[2 * i] = a * c - b * s;
         v[2 * i + 1] = a * s + b * c;
     }
+}
+
+/* One int8 product on its own, for the operator-level tests: W [N][K] float is quantised per row as the engine does
+ * (q8_register), A [M][K] per the scheme (0 block, 1 dynamic uint8).  The registry entry is dropped afterwards. */
+void ptts_oracle_q8_linear(const float *A, int M, int K, const float *W, int N, int scheme, float *out) {
+    const int saved = g_q8_act;
+    g_q8_act = scheme;
+    q8_register(W, N, K);
+    g_q8_act = saved;
+    const Q8Entry *e = q8_find(W);
+    if (!e) { memset(out, 0, (size_t)M * N * sizeof(float)); return; }
+    linear_q8(out, N, A, K, e, NULL, M);
+    q8_forget((const unsigned char *)W, (const unsigned char *)W + 1);
 }
 
 /* ------------------------------------------------------------------ transformer (shared by LM and Mimi) */

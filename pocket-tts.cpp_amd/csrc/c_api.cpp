@@ -584,6 +584,14 @@ POCKET_TTS_API int ptts_q8_linear(PocketTTSHandle handle, const float* A, int M,
     });
 }
 
+POCKET_TTS_API int ptts_q8_linear_dyn(PocketTTSHandle handle, const float* A, int M, int K, const float* W, int N, float* out) {
+    if (!handle || !A || !W || !out || M <= 0 || N <= 0 || K <= 0) { set_error("Invalid parameters"); return -1; }
+    return guarded("q8_linear_dyn: ", [&] {
+        tts_of(handle)->engine().q8_linear(A, M, K, W, N, out, nullptr, nullptr, 1);
+        return 0;
+    });
+}
+
 POCKET_TTS_API int ptts_q8_linear_q(PocketTTSHandle handle, const float* A, int M, int K, const signed char* q, const float* scale, int N,
                                     float* out) {
     if (!handle || !A || !q || !scale || !out || M <= 0 || N <= 0 || K <= 0) { set_error("Invalid parameters"); return -1; }

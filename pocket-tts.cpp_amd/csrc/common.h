@@ -35,6 +35,7 @@ struct Spec {
     int mimi_dim = 0, mimi_layers = 0, mimi_heads = 0, mimi_ffn = 0, mimi_context = 0, mimi_max_period = 0;
     int n_filters = 0, ratios[3] = {0, 0, 0}, kernel = 0, last_kernel = 0, res_kernel = 0, upsample = 0;
     int sample_rate = 0;
+    int q8_act_scheme = 0;   // int8 engine's activation scheme: 0 per row and 64-block symmetric int8, 1 ONNX dynamic uint8 with zero point
     float lm_eps = 0, flow_eps = 0, mimi_eps = 0, flow_max_period = 0;
     int frame_size() const { return upsample * ratios[0] * ratios[1] * ratios[2]; }
 };

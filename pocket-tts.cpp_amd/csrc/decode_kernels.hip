@@ -295,6 +295,140 @@ __global__ __launch_bounds__(256) void skinny_q8_kernel(SkinnyArgs a) {
     }
 }
 
+// ---- int8 weights x dynamically quantised uint8 activations with a zero point (q8_act = 1) -----------------------
+// The activation scheme of ONNX DynamicQuantizeLinear + MatMulInteger, which is what a dynamically quantised ONNX graph
+// (the reference's *_int8.onnx files, src/pocket_tts.cpp:90-96) applies to every matrix input.  Per row (the reference runs
+// one utterance per call, so a decode step's activation tensor IS one row):
+//     lo = min(0, min a), hi = max(0, max a), s = (hi - lo) / 255, zp = rint(clamp(-lo / s, 0, 255)),
+//     q = clamp(rint(a / s) + zp, 0, 255)                                    (rint: round half to even; s = 0 -> q = zp = 0)
+//     y[n] = (float)(sum_k (q[k] - zp) * w[n][k]) * (s * wscale[n]) + bias[n]
+// The matrix instruction multiplies signed bytes, so the row is staged as q - 128 and the integer sum is corrected by
+// (128 - zp) * (sum_k w[n][k]), the weight row sums (SkinnyArgs::wsum) being formed once when the matrix is loaded: the
+// whole sum stays in int32 and is exact.  A workgroup first forms lo / hi of its rows over the full K (every K-slice
+// workgroup repeats that), then streams its K-slice as skinny_q8_kernel does.  With K-slices wsum is [slices][N], each
+// slice corrects its own part of the sum and writes an already scaled slab (the consumer adds the slabs in f32).
+template <int MT>
+__global__ __launch_bounds__(256) void skinny_q8o_kernel(SkinnyArgs a) {
+    constexpr int ROWS = 16 * MT;
+    constexpr int KSTEP = 64, KCH = 128, LDA = KCH + 16, NKS = KCH / KSTEP, PIECES = KCH / 4, APT = ROWS * PIECES / 256;
+    __shared__ __attribute__((aligned(16))) signed char As[2][ROWS * LDA];
+    __shared__ float row_s[ROWS];
+    __shared__ int row_zp[ROWS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockIdx.x * 4 + wave;
+    const bool tile_live = nt * 16 < a.N;
+    const int m0 = blockIdx.z * ROWS;
+    const int Kc = a.K / a.splits;
+    const int k_begin = blockIdx.y * Kc;
+    const int nchunks = (Kc + KCH - 1) / KCH;
+    const int KS_total = a.K / KSTEP;
+    const uint4* wbase = (const uint4*)a.Wp + (long long)nt * KS_total * 64 + lane;
+
+    // ---- row statistics over the full K: wave w takes rows w, w + 4, ...
+    for (int rr = wave; rr < ROWS; rr += 4) {
+        float lo = 0.f, hi = 0.f;
+        if (m0 + rr < a.M) {
+            const float* ar = a.A + (long long)(m0 + rr) * a.lda;
+            for (int k = 4 * lane; k < a.K; k += 256) {
+                const float4 v = *(const float4*)(ar + k);
+                lo = fminf(lo, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+                hi = fmaxf(hi, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            }
+        }
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) { lo = fminf(lo, __shfl_xor(lo, of, 64)); hi = fmaxf(hi, __shfl_xor(hi, of, 64)); }
+        if (lane == 0) {
+            const float sc = (hi - lo) / 255.0f;
+            const bool flat = !(sc > 0.f);
+            row_s[rr] = flat ? 0.f : sc;
+            row_zp[rr] = flat ? 0 : (int)rintf(fminf(fmaxf(-lo / sc, 0.f), 255.f));
+        }
+    }
+    __syncthreads();
+
+    float4 areg[APT];
+    uint4 bnext[NKS], bcur[NKS];
+    auto load_chunk = [&](int c) {
+        const int kc0 = c * KCH;
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int id = tid + 256 * i, row = id / PIECES, piece = id % PIECES;
+            const int k = kc0 + piece * 4;
+            const bool ok = (m0 + row) < a.M && k < Kc;
+            areg[i] = ok ? *(const float4*)(a.A + (long long)(m0 + row) * a.lda + k_begin + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NKS; ++i) {
+            const int k = kc0 + i * KSTEP;
+            bnext[i] = (tile_live && k < Kc) ? wbase[(long long)((k_begin + k) / KSTEP) * 64] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto quant1 = [](float v, float sc, int zp) -> int {   // x / s, as the operator is specified (a true division)
+        int q = (int)rintf(v / sc) + zp;
+        q = q < 0 ? 0 : (q > 255 ? 255 : q);
+        return (q - 128) & 0xff;
+    };
+
+    i32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = i32x4{0, 0, 0, 0};
+    const int r = lane & 15, g = lane >> 4;
+
+    load_chunk(0);
+    for (int c = 0; c < nchunks; ++c) {
+        signed char* buf = As[c & 1];
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int id = tid + 256 * i, row = id / PIECES, piece = id % PIECES;
+            const float sc = row_s[row];
+            const int zp = row_zp[row];
+            unsigned pk;
+            if (sc > 0.f) {
+                pk = (unsigned)quant1(areg[i].x, sc, zp) | ((unsigned)quant1(areg[i].y, sc, zp) << 8) | ((unsigned)quant1(areg[i].z, sc, zp) << 16) |
+                     ((unsigned)quant1(areg[i].w, sc, zp) << 24);
+            } else {
+                pk = 0x80808080u;   // q = zp = 0 -> staged as -128; the correction term cancels it exactly
+            }
+            // rows past M and columns past the slice were loaded as 0.0: they quantise to zp, i.e. contribute (zp - zp) = 0
+            *(unsigned*)(buf + row * LDA + piece * 4) = pk;
+        }
+#pragma unroll
+        for (int i = 0; i < NKS; ++i) bcur[i] = bnext[i];
+        __syncthreads();
+        if (c + 1 < nchunks) load_chunk(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const i32x4 b4 = __builtin_bit_cast(i32x4, bcur[ks]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const i32x4 a4 = *(const i32x4*)(buf + (mt * 16 + r) * LDA + ks * 64 + 16 * g);
+                acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a4, b4, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    if (!tile_live) return;
+    const int col = nt * 16 + r;
+    const float ws = a.wscale[col];
+    const int wsum = a.wsum[(long long)blockIdx.y * a.N + col];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = mt * 16 + g * 4 + i, row = m0 + rl;
+            if (row >= a.M) continue;
+            const int total = acc[mt][i] + (128 - row_zp[rl]) * wsum;
+            float v = __fmul_rn((float)total, __fmul_rn(row_s[rl], ws));
+            if (a.P) {
+                a.P[((long long)blockIdx.y * a.M + row) * a.N + col] = v;
+            } else {
+                if (a.bias) v = __fadd_rn(v, a.bias[col]);
+                a.C[(long long)row * a.ldc + col] = act_dev(v, a.act);
+            }
+        }
+    }
+}
+
 // The same product with activations that arrive quantised (SkinnyArgs::Aq / Ad): nothing is staged.  A wave's A
 // fragment of k-step ks is 16 bytes per lane straight from the int8 rows (lane (r, g): row m0 + r, k = 64 ks + 16 g ..),
 // its scales one float4 of Ad[ks][m0 + 4 g ..]; with the weight fragment that is three independent loads per k-step and no
@@ -393,7 +527,7 @@ __global__ __launch_bounds__(256) void skinny_q8p_kernel(SkinnyArgs a) {
 
 // int8 fragment-major packing: tile (nt, ks) holds, for lane l, the 16 consecutive k-values ks*64 + 16*(l>>4) ..
 // of output column nt*16 + (l&15).
-std::vector<unsigned char> pack_q8_weight(const float* W, int N, int K, std::vector<float>& scale) {
+std::vector<signed char> quantize_q8_rows(const float* W, int N, int K, std::vector<float>& scale) {
     if (N % 16 || K % 64) throw std::runtime_error("int8 weight: N must be a multiple of 16 and K of 64");
     scale.assign(N, 0.f);
     std::vector<signed char> q((size_t)N * K);
@@ -408,7 +542,26 @@ std::vector<unsigned char> pack_q8_weight(const float* W, int N, int K, std::vec
             q[(size_t)n * K + k] = (signed char)rv;
         }
     }
+    return q;
+}
+
+std::vector<unsigned char> pack_q8_weight(const float* W, int N, int K, std::vector<float>& scale) {
+    const std::vector<signed char> q = quantize_q8_rows(W, N, K, scale);
     return pack_q8_layout(q.data(), N, K);
+}
+
+// sums[s][n] = sum over K-slice s of q[n][k]  (the zero-point correction of the dynamic uint8 activation scheme)
+std::vector<int> q8_row_sums(const signed char* q, int N, int K, int splits) {
+    if (splits < 1 || K % splits) throw std::runtime_error("int8 weight: K-slices must divide K");
+    std::vector<int> out((size_t)splits * N, 0);
+    const int Kc = K / splits;
+    for (int n = 0; n < N; ++n)
+        for (int sl = 0; sl < splits; ++sl) {
+            int acc = 0;
+            for (int k = 0; k < Kc; ++k) acc += q[(size_t)n * K + (size_t)sl * Kc + k];
+            out[(size_t)sl * N + n] = acc;
+        }
+    return out;
 }
 
 std::vector<unsigned char> pack_q8_layout(const signed char* q, int N, int K) {
@@ -667,6 +820,7 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
         while (mt > 1 && cols * ((a.M + 16 * mt - 1) / (16 * mt)) < 512) mt >>= 1;
         if (a.M <= 16 * (mt / 2)) mt = a.M <= 16 ? 1 : 2;     // never stage rows that do not exist
     }
+    if (a.Aq && a.q8_act == 1) throw std::runtime_error("skinny gemm: pre-quantised rows exist in the block scheme only");
     if (a.Aq) {
         if (a.wtype != W_I8 || !a.Ad || a.Mq < ((a.M + 15) & ~15) || (a.Mq & 3) || (a.ldaq & 15) || ((uintptr_t)a.Aq & 15) || ((uintptr_t)a.Ad & 15))
             throw std::runtime_error("skinny gemm: quantised activations need int8 weights, scales [K/64][Mq] and 16-byte aligned rows");
@@ -678,6 +832,14 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
     if (a.Cq) throw std::runtime_error("skinny gemm: a quantised result is produced from quantised activations only");
     if ((a.colscale || a.R) && (a.P || a.wtype == W_I8)) throw std::runtime_error("skinny gemm: column scale and residual belong to the f32 / bf16 C form");
     grid.z = (a.M + 16 * mt - 1) / (16 * mt);
+    if (a.wtype == W_I8 && a.q8_act == 1) {
+        if (!a.wsum) throw std::runtime_error("skinny gemm: the dynamic uint8 activation scheme needs the weight row sums");
+        if (a.lda % 4 || a.K % 4) throw std::runtime_error("skinny gemm: rows must be 16-byte aligned for the dynamic uint8 scheme");
+        if (mt == 1) hipLaunchKernelGGL(skinny_q8o_kernel<1>, grid, block, 0, s, a);
+        else if (mt == 2) hipLaunchKernelGGL(skinny_q8o_kernel<2>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(skinny_q8o_kernel<4>, grid, block, 0, s, a);
+        return;
+    }
     if (a.wtype == W_I8) {
         if (mt == 1) hipLaunchKernelGGL(skinny_q8_kernel<1>, grid, block, 0, s, a);
         else if (mt == 2) hipLaunchKernelGGL(skinny_q8_kernel<2>, grid, block, 0, s, a);

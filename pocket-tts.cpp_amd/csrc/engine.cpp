@@ -203,7 +203,11 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     flow_wtype = prec_ != Precision::FP32 ? W_BF16 : W_F32;
     const bool q8 = prec_ == Precision::INT8;
     lm_wtype = q8 ? W_I8 : flow_wtype;
-    flow_block_wtype = (q8 && s.flow_dim % 256 == 0) ? W_I8 : flow_wtype;   // narrower heads keep bf16 blocks
+    q8_act = s.q8_act_scheme == 1 ? 1 : 0;
+    if (const char* e = std::getenv("POCKET_TTS_Q8_ACT")) q8_act = std::string(e) == "dyn" ? 1 : 0;
+    if (!q8) q8_act = 0;
+    // narrower heads keep bf16 blocks; so does the dynamic uint8 scheme (the persistent head quantises per block of 64 only)
+    flow_block_wtype = (q8 && q8_act == 0 && s.flow_dim % 256 == 0) ? W_I8 : flow_wtype;
     two_term = two_term_families(prec_, flow_block_wtype == W_I8);
     // second plane of a two-term matrix in the fragment-major layout of the skinny / flow kernels
     auto packed_lo = [&](const float* W, int N, int K) -> const void* {
@@ -228,18 +232,33 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
         split_[name] = {static_cast<const unsigned char*>(blob_lp_.p) + entries_[name].off_lp, extra_.back().p};
     };
     // int8 form of a matrix: fragment-major int8 values + per-output-row scales, both uploaded
-    auto packed_q8 = [&](const std::string& name, const float*& scale_dev) -> const void* {
+    auto packed_q8 = [&](const std::string& name, const float*& scale_dev, const int** wsums = nullptr) -> const void* {
         const HostTensor& t = pack.get(name);
         std::vector<float> sc;
         std::vector<unsigned char> bytes;
+        std::vector<signed char> requant;
+        const signed char* qv = nullptr;
+        const int N = static_cast<int>(t.shape[0]), K = static_cast<int>(t.shape[1]);
         // a matrix that is int8 at the source is used as it is (values and per-row scales); POCKET_TTS_REQUANTIZE=1
         // quantises the f32 tensor again instead
         const Q8Tensor* carried = std::getenv("POCKET_TTS_REQUANTIZE") ? nullptr : pack.q8(name);
         if (carried) {
-            bytes = pack_q8_layout(reinterpret_cast<const signed char*>(carried->q), carried->N, carried->K);
+            qv = reinterpret_cast<const signed char*>(carried->q);
             sc.assign(carried->scale, carried->scale + carried->N);
         } else {
-            bytes = pack_q8_weight(t.data, static_cast<int>(t.shape[0]), static_cast<int>(t.shape[1]), sc);
+            requant = quantize_q8_rows(t.data, N, K, sc);
+            qv = requant.data();
+        }
+        bytes = pack_q8_layout(qv, N, K);
+        if (wsums && q8_act == 1) {   // weight row sums per K-slice, for every slice count the passes use
+            for (int j = 0; j < 5; ++j) {
+                const int sp = 1 << j;
+                if ((K / 64) % sp) continue;
+                const std::vector<int> sums = q8_row_sums(qv, N, K, sp);
+                extra_.emplace_back(sums.size() * 4);
+                sync_copy(extra_.back().p, sums.data(), sums.size() * 4, hipMemcpyHostToDevice);
+                wsums[j] = static_cast<const int*>(extra_.back().p);
+            }
         }
         extra_.emplace_back(bytes.size());
         sync_copy(extra_.back().p, bytes.data(), bytes.size(), hipMemcpyHostToDevice);
@@ -338,8 +357,8 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
         std::string p = "lm.l" + std::to_string(i) + ".";
         PackedLayer pl;
         if (q8) {
-            pl.qkv = packed_q8(p + "qkv.w", pl.s_qkv); pl.out = packed_q8(p + "out.w", pl.s_out);
-            pl.ff1 = packed_q8(p + "ff1.w", pl.s_ff1); pl.ff2 = packed_q8(p + "ff2.w", pl.s_ff2);
+            pl.qkv = packed_q8(p + "qkv.w", pl.s_qkv, pl.ws_qkv); pl.out = packed_q8(p + "out.w", pl.s_out, pl.ws_out);
+            pl.ff1 = packed_q8(p + "ff1.w", pl.s_ff1, pl.ws_ff1); pl.ff2 = packed_q8(p + "ff2.w", pl.s_ff2, pl.ws_ff2);
         } else {
             pl.qkv = packed(p + "qkv.w"); pl.out = packed(p + "out.w"); pl.ff1 = packed(p + "ff1.w"); pl.ff2 = packed(p + "ff2.w");
             if (two_term.count("lm.qkv")) { pl.qkv_lo = packed_lo_named(p + "qkv.w"); rowmajor_lo(p + "qkv.w"); }
@@ -1004,6 +1023,16 @@ void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc,
     check_launches("the transformer pass");
 }
 
+// The dynamic uint8 scheme of an int8 product: weight row sums for the product's slice count (a power of two up to 16).
+static void bind_q8_act(SkinnyArgs& k, int scheme, const int* const* wsums) {
+    if (scheme != 1 || k.wtype != W_I8) return;
+    int j = 0;
+    while ((1 << j) < k.splits && j < 4) ++j;
+    if ((1 << j) != k.splits || !wsums[j]) throw std::runtime_error("int8 product: no weight row sums for this K-slice count");
+    k.q8_act = 1;
+    k.wsum = wsums[j];
+}
+
 // K-slices for a split-K product: about 256 deep each, at most 8, dividing K into k-step multiples.
 static int pick_splits(int K, int kstep) {
     int s = K / 256;
@@ -1062,6 +1091,7 @@ void Engine::lm_rows_skinny(Batch& b, int slot0, int nb, int rpb, float* X) {
         const Model::PackedLayer& pw = model_->lm_packed[l];
         SkinnyArgs q;
         q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.Wp2 = pw.qkv_lo; q.wtype = wt; q.wscale = pw.s_qkv; q.M = M; q.N = 3 * D; q.K = D; q.C = b.qkv.f(); q.ldc = 3 * D;
+        bind_q8_act(q, model_->q8_act, pw.ws_qkv);
         launch_skinny_gemm(q, st);
         RopeAppendArgs r;
         const long long kv_off = static_cast<long long>(l) * layer_stride * (b.kv16 ? 2 : 4);
@@ -1075,6 +1105,7 @@ void Engine::lm_rows_skinny(Batch& b, int slot0, int nb, int rpb, float* X) {
         launch_attention(at, st);
         SkinnyArgs o;
         o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.Wp2 = pw.out_lo; o.wtype = wt; o.wscale = pw.s_out; o.M = M; o.N = D; o.K = D; o.splits = s_out; o.P = b.pre_partial.f();
+        bind_q8_act(o, model_->q8_act, pw.ws_out);
         launch_skinny_gemm(o, st);
         AddNormArgs a1 = an;
         a1.P = b.pre_partial.f(); a1.splits = s_out; a1.colscale = w.ls1; a1.g = w.ln2g; a1.b = w.ln2b;
@@ -1082,9 +1113,11 @@ void Engine::lm_rows_skinny(Batch& b, int slot0, int nb, int rpb, float* X) {
         SkinnyArgs f1;
         f1.A = b.h.f(); f1.lda = D; f1.Wp = pw.ff1; f1.wtype = wt; f1.wscale = pw.s_ff1; f1.M = M; f1.N = F; f1.K = D; f1.act = ACT_GELU;
         f1.C = b.ff.f(); f1.ldc = F;
+        bind_q8_act(f1, model_->q8_act, pw.ws_ff1);
         launch_skinny_gemm(f1, st);
         SkinnyArgs f2;
         f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.Wp2 = pw.ff2_lo; f2.wtype = wt; f2.wscale = pw.s_ff2; f2.M = M; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.pre_partial.f();
+        bind_q8_act(f2, model_->q8_act, pw.ws_ff2);
         launch_skinny_gemm(f2, st);
         AddNormArgs a2 = an;
         a2.P = b.pre_partial.f(); a2.splits = s_ff2; a2.colscale = w.ls2;
@@ -1126,7 +1159,8 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
     if (b.partial.bytes < static_cast<size_t>(std::max(s_out, s_ff2)) * B * D * 4) throw std::runtime_error("split-K slab buffer too small");
     // int8 engine: every matrix input of the step is quantised by the kernel that produces it (add & norm, attention,
     // the FFN-1 epilogue), so the products read int8 rows and stage nothing
-    const bool preq = wt == W_I8 && b.q_rows > 0 && !std::getenv("POCKET_TTS_Q8_STAGED");
+    // (block scheme only: in the dynamic uint8 scheme the products quantise their rows themselves)
+    const bool preq = wt == W_I8 && model_->q8_act == 0 && b.q_rows > 0 && !std::getenv("POCKET_TTS_Q8_STAGED");
     AddNormArgs an;
     an.X = b.x.f(); an.ldx = D; an.M = B; an.D = D; an.eps = s.lm_eps;
     an.g = hd_.lm[0].ln1g; an.b = hd_.lm[0].ln1b; an.H = b.h.f();
@@ -1144,6 +1178,7 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         q.A = b.h.f(); q.lda = D; q.Wp = pw.qkv; q.Wp2 = pw.qkv_lo; q.wtype = wt; q.wscale = pw.s_qkv; q.M = B; q.N = 3 * D; q.K = D;
         q.splits = s_qkv; q.P = b.qkv.f();   // K-slice slabs, summed where the attention kernel reads them
         if (preq) { q.A = nullptr; q.Aq = b.hq.as<signed char>(); q.ldaq = D; q.Ad = b.hd.f(); q.Mq = b.q_rows; }
+        bind_q8_act(q, model_->q8_act, pw.ws_qkv);
         launch_skinny_gemm(q, b.st);
         AttnDecodeArgs at;
         const long long kv_off = static_cast<long long>(l) * layer_stride * (b.kv16 ? 2 : 4);
@@ -1156,6 +1191,7 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         SkinnyArgs o;
         o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.Wp2 = pw.out_lo; o.wtype = wt; o.wscale = pw.s_out; o.M = B; o.N = D; o.K = D; o.splits = s_out; o.P = b.partial.f();
         if (preq) { o.A = nullptr; o.Aq = b.attq.as<signed char>(); o.ldaq = D; o.Ad = b.attd.f(); o.Mq = b.q_rows; }
+        bind_q8_act(o, model_->q8_act, pw.ws_out);
         launch_skinny_gemm(o, b.st);
         AddNormArgs a1 = an;
         a1.P = b.partial.f(); a1.splits = s_out; a1.colscale = w.ls1; a1.g = w.ln2g; a1.b = w.ln2b;
@@ -1167,10 +1203,12 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
             f1.A = nullptr; f1.Aq = b.hq.as<signed char>(); f1.ldaq = D; f1.Ad = b.hd.f(); f1.Mq = b.q_rows;
             f1.C = nullptr; f1.Cq = b.ffq.as<signed char>(); f1.Cd = b.ffd.f();
         }
+        bind_q8_act(f1, model_->q8_act, pw.ws_ff1);
         launch_skinny_gemm(f1, b.st);
         SkinnyArgs f2;
         f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.Wp2 = pw.ff2_lo; f2.wtype = wt; f2.wscale = pw.s_ff2; f2.M = B; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.partial.f();
         if (preq) { f2.A = nullptr; f2.Aq = b.ffq.as<signed char>(); f2.ldaq = F; f2.Ad = b.ffd.f(); f2.Mq = b.q_rows; }
+        bind_q8_act(f2, model_->q8_act, pw.ws_ff2);
         launch_skinny_gemm(f2, b.st);
         AddNormArgs a2 = an;
         a2.P = b.partial.f(); a2.splits = s_ff2; a2.colscale = w.ls2;

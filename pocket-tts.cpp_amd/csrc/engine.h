@@ -83,7 +83,10 @@ public:
         const void *qkv, *out, *ff1, *ff2;
         const float *s_qkv = nullptr, *s_out = nullptr, *s_ff1 = nullptr, *s_ff2 = nullptr;
         const void *qkv_lo = nullptr, *out_lo = nullptr, *ff2_lo = nullptr;   // second planes of two-term bf16 matrices (null: one term)
+        // int8 matrices in the dynamic uint8 activation scheme: per K-slice sums of each weight row, for 1, 2, 4, 8 and 16 slices
+        const int *ws_qkv[5] = {}, *ws_out[5] = {}, *ws_ff1[5] = {}, *ws_ff2[5] = {};
     };
+    int q8_act = 0;   // int8 engine's activation scheme (Spec::q8_act_scheme, POCKET_TTS_Q8_ACT=block|dyn overrides)
     std::set<std::string> two_term;   // matrix families held as two bf16 terms (see two_term_families in engine.cpp)
     int lm_wtype = W_F32;        // weight type of lm_packed (W_I8 in int8 mode)
     int flow_block_wtype = W_F32;
@@ -225,7 +228,8 @@ public:
     void op_flow_euler_static(const float* cond_dev, const float* x0_dev, int B, float* x_out_dev);
     static size_t static_scratch_capacity();
     void op_mimi_decode(Batch* b, const float* latents /*[B][n][latent]*/, int n, float* audio /*[B][n*frame]*/);
-    void q8_linear(const float* A, int M, int K, const float* W, int N, float* out, const signed char* q = nullptr, const float* qscale = nullptr);   // the int8 product kernel alone
+    // the int8 product kernel alone; scheme: 0 per row and block of 64, 1 dynamic uint8 with zero point
+    void q8_linear(const float* A, int M, int K, const float* W, int N, float* out, const signed char* q = nullptr, const float* qscale = nullptr, int scheme = 0);
     void bf16_linear(const float* A, int M, int K, const float* W, int N, const float* bias, const float* colscale, const float* R, int act,
                      int flags, float* out);   // the bf16 GEMM dispatch alone
 

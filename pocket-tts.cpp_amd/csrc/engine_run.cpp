@@ -800,19 +800,23 @@ void Engine::op_flow_euler(const float* cond, const float* x0, int B, float* x_o
 }
 
 // W given: quantised here per output row; else q / qscale are the int8 values [N][K] and their per-row scales as they are.
-void Engine::q8_linear(const float* A, int M, int K, const float* W, int N, float* out, const signed char* q, const float* qscale) {
+void Engine::q8_linear(const float* A, int M, int K, const float* W, int N, float* out, const signed char* q, const float* qscale, int scheme) {
     std::lock_guard<std::mutex> guard(mu_);
     PTTS_HIP(hipSetDevice(opt_.device));
     std::vector<float> scale;
-    std::vector<unsigned char> wq;
-    if (W) wq = pack_q8_weight(W, N, K, scale);
-    else { wq = pack_q8_layout(q, N, K); scale.assign(qscale, qscale + N); }
-    DevBuf dA(static_cast<size_t>(M) * K * 4), dW(wq.size()), dS(scale.size() * 4), dC(static_cast<size_t>(M) * N * 4);
+    std::vector<signed char> qv;
+    if (W) qv = quantize_q8_rows(W, N, K, scale);
+    else { qv.assign(q, q + static_cast<size_t>(N) * K); scale.assign(qscale, qscale + N); }
+    const std::vector<unsigned char> wq = pack_q8_layout(qv.data(), N, K);
+    const std::vector<int> sums = q8_row_sums(qv.data(), N, K, 1);
+    DevBuf dA(static_cast<size_t>(M) * K * 4), dW(wq.size()), dS(scale.size() * 4), dC(static_cast<size_t>(M) * N * 4), dU(sums.size() * 4);
     PTTS_HIP(hipMemcpyAsync(dA.p, A, dA.bytes, hipMemcpyHostToDevice, stream_));
     PTTS_HIP(hipMemcpyAsync(dW.p, wq.data(), wq.size(), hipMemcpyHostToDevice, stream_));
     PTTS_HIP(hipMemcpyAsync(dS.p, scale.data(), scale.size() * 4, hipMemcpyHostToDevice, stream_));
+    PTTS_HIP(hipMemcpyAsync(dU.p, sums.data(), sums.size() * 4, hipMemcpyHostToDevice, stream_));
     SkinnyArgs g;
     g.A = dA.f(); g.lda = K; g.Wp = dW.p; g.wtype = W_I8; g.wscale = dS.f(); g.M = M; g.N = N; g.K = K; g.C = dC.f(); g.ldc = N;
+    if (scheme == 1) { g.q8_act = 1; g.wsum = dU.as<int>(); }
     launch_skinny_gemm(g, stream_);
     PTTS_HIP(hipMemcpyAsync(out, dC.p, dC.bytes, hipMemcpyDeviceToHost, stream_));
     PTTS_HIP(hipStreamSynchronize(stream_));

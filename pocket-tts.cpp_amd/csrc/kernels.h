@@ -237,6 +237,10 @@ std::vector<unsigned char> pack_flow_weight(const float* W, int N, int K, int wt
 std::vector<unsigned char> pack_q8_weight(const float* W, int N, int K, std::vector<float>& scale);
 // The layout step alone, for int8 values that come with their own scales (a pack's `<name>.q8` form).
 std::vector<unsigned char> pack_q8_layout(const signed char* q, int N, int K);
+// sums[s][n] = sum over K-slice s of q[n][k], for SkinnyArgs::wsum
+std::vector<int> q8_row_sums(const signed char* q, int N, int K, int splits);
+// the int8 values pack_q8_weight derives from a float matrix (before the layout step)
+std::vector<signed char> quantize_q8_rows(const float* W, int N, int K, std::vector<float>& scale);
 
 // ---- batched decode step (decode_kernels.hip) -----------------------------------------------------
 // C[M][N] = A[M][K] * W^T with f32 A and W fragment-major (pack_flow_weight layout, f32 or bf16).
@@ -253,6 +257,10 @@ struct SkinnyArgs {
     // C form only (f32 / bf16 weights): C = act(acc + bias) * colscale + R
     const float* colscale = nullptr; const float* R = nullptr; int ldr = 0;
     const float* wscale = nullptr;   // W_I8: per-output-column weight scale
+    // W_I8, activation scheme.  0: per row and block of 64 k, symmetric int8 (s = max|a|, q = rint(a * 127 / s)).
+    // 1: ONNX DynamicQuantizeLinear per row: uint8 with a zero point over [min(0, min a), max(0, max a)]; needs
+    // wsum[splits][N] = per K-slice sums of each weight row (q8_row_sums).
+    int q8_act = 0; const int* wsum = nullptr;
     int a_frag = 0;                  // A holds two-term bf16 fragments (launch_flow_mod_input's frag form); only where skinny_wide_rows_applies()
     int mtiles = 0;                  // 16-row tiles per workgroup: 1, 2 or 4 (0 = 4)
     int kchunk = 0;                  // K elements staged per step: 128, 256 or 512 (bf16, mtiles <= 2); 0 = 128

@@ -105,7 +105,7 @@ Pack::Pack(const std::string& path) {
     s.mimi_dim = iv[10]; s.mimi_layers = iv[11]; s.mimi_heads = iv[12]; s.mimi_ffn = iv[13];
     s.mimi_context = iv[14]; s.mimi_max_period = iv[15]; s.n_filters = iv[16];
     s.ratios[0] = iv[17]; s.ratios[1] = iv[18]; s.ratios[2] = iv[19];
-    s.kernel = iv[20]; s.last_kernel = iv[21]; s.res_kernel = iv[22]; s.upsample = iv[23]; s.sample_rate = iv[24];
+    s.kernel = iv[20]; s.last_kernel = iv[21]; s.res_kernel = iv[22]; s.upsample = iv[23]; s.sample_rate = iv[24]; s.q8_act_scheme = iv[25];
     s.lm_eps = fv[0]; s.flow_eps = fv[1]; s.mimi_eps = fv[2]; s.flow_max_period = fv[3];
     if (kHeaderSize + static_cast<size_t>(n) * sizeof(RawEntry) > blob_.size())
         throw std::runtime_error("weight pack tensor table truncated");

@@ -51,7 +51,7 @@ EXT_SYMBOLS = [
     "pocket_tts_stage_ids", "pocket_tts_run_staged", "pocket_tts_fetch_staged",
     "pocket_tts_tokenize", "ptts_text_conditioner", "ptts_state_new", "ptts_state_free", "ptts_state_reset",
     "ptts_lm_prefill", "ptts_lm_step", "ptts_flow_euler", "ptts_flow_euler_noalloc", "ptts_flow_euler_noalloc_capacity", "ptts_mimi_decode", "ptts_mimi_encode", "ptts_mimi_encode_batch",
-    "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_scheduler_stats_ex", "ptts_engine_count", "ptts_q8_linear", "ptts_q8_linear_q", "ptts_bf16_linear",
+    "ptts_phase_timing", "ptts_phase_times", "ptts_weight_bytes", "ptts_scheduler_stats", "ptts_scheduler_stats_ex", "ptts_engine_count", "ptts_q8_linear", "ptts_q8_linear_q", "ptts_q8_linear_dyn", "ptts_bf16_linear",
     "ptts_tokenizer_new", "ptts_tokenizer_free", "ptts_tokenizer_vocab", "ptts_tokenizer_encode",
     "ptts_audio_load_wav", "ptts_audio_save_wav", "ptts_audio_resample", "ptts_audio_normalize",
     "ptts_onnx_open", "ptts_onnx_close", "ptts_onnx_tensor_count", "ptts_onnx_tensor_info", "ptts_onnx_find",
@@ -122,6 +122,7 @@ def load() -> C.CDLL:
     L.ptts_scheduler_stats_ex.restype = ci; L.ptts_scheduler_stats_ex.argtypes = [vp, C.POINTER(C.c_long)]
     L.ptts_q8_linear.restype = ci; L.ptts_q8_linear.argtypes = [vp, f32p, ci, ci, f32p, ci, f32p]
     L.ptts_engine_count.restype = ci; L.ptts_engine_count.argtypes = [vp, C.POINTER(C.c_long), ci]
+    L.ptts_q8_linear_dyn.restype = ci; L.ptts_q8_linear_dyn.argtypes = [vp, f32p, ci, ci, f32p, ci, f32p]
     L.ptts_q8_linear_q.restype = ci; L.ptts_q8_linear_q.argtypes = [vp, f32p, ci, ci, vp, f32p, ci, f32p]
     L.ptts_bf16_linear.restype = ci
     L.ptts_bf16_linear.argtypes = [vp, f32p, ci, ci, f32p, ci, vp, vp, vp, ci, ci, f32p]
@@ -463,11 +464,13 @@ class Engine:
         _check(self.L.ptts_phase_times(self.h, t, c), "phase_times")
         return dict(lm_ms=t[0], flow_ms=t[1], dec_ms=t[2], head_ms=t[3], lm_calls=c[0], flow_calls=c[1], dec_calls=c[2], head_calls=c[3])
 
-    def q8_linear(self, A, W) -> np.ndarray:
+    def q8_linear(self, A, W, dynamic=False) -> np.ndarray:
+        """A . W^T on the int8 kernel; dynamic=True: rows of A as uint8 with a zero point over the whole row."""
         A = np.ascontiguousarray(A, np.float32)
         W = np.ascontiguousarray(W, np.float32)
         out = np.empty((A.shape[0], W.shape[0]), np.float32)
-        _check(self.L.ptts_q8_linear(self.h, A, A.shape[0], A.shape[1], W, W.shape[0], out), "q8_linear")
+        fn = self.L.ptts_q8_linear_dyn if dynamic else self.L.ptts_q8_linear
+        _check(fn(self.h, A, A.shape[0], A.shape[1], W, W.shape[0], out), "q8_linear")
         return out
 
     def q8_linear_q(self, A, q, scale) -> np.ndarray:

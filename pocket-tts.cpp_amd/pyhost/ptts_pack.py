@@ -34,7 +34,7 @@ SPEC_INT_FIELDS = [
     "flow_dim", "flow_blocks", "flow_freq_dim",
     "mimi_dim", "mimi_layers", "mimi_heads", "mimi_ffn", "mimi_context", "mimi_max_period",
     "n_filters", "ratio0", "ratio1", "ratio2", "kernel", "last_kernel", "res_kernel",
-    "upsample", "sample_rate",
+    "upsample", "sample_rate", "q8_act_scheme",
 ]
 SPEC_FLOAT_FIELDS = ["lm_ln_eps", "flow_ln_eps", "mimi_ln_eps", "flow_max_period"]
 
@@ -67,6 +67,10 @@ class Spec:
     res_kernel: int = 3
     upsample: int = 16
     sample_rate: int = 24000
+    # activation scheme of the int8 engine: 0 = per row and block of 64, symmetric int8 (this build's own); 1 = the dynamic
+    # uint8-with-zero-point scheme of ONNX DynamicQuantizeLinear + MatMulInteger (what a dynamically quantised ONNX export of
+    # the model applies; tools/onnx_to_ptts.py sets it when the int8 graphs contain those operators)
+    q8_act_scheme: int = 0
     lm_ln_eps: float = 1e-5
     flow_ln_eps: float = 1e-6
     mimi_ln_eps: float = 1e-5
@@ -372,21 +376,23 @@ def bf16_model(weights: Dict[str, np.ndarray], two_term=TWO_TERM_DEFAULT) -> Dic
     return {k: (bf16_round(v) if rounded(k) else v) for k, v in weights.items()}
 
 
-def is_int8_weight(name: str, flow_dim: int = 512) -> bool:
+def is_int8_weight(name: str, flow_dim: int = 512, scheme: int = 0) -> bool:
     """Matrices the int8 engine holds as int8 (per-output-channel scale): LM layers and, when flow_dim is a
-    multiple of 256, the flow residual blocks."""
+    multiple of 256 and the activation scheme is the per-block one (scheme 0), the flow residual blocks."""
     if name.startswith("lm.l") and name.endswith((".qkv.w", ".out.w", ".ff1.w", ".ff2.w")):
         return True
-    return flow_dim % 256 == 0 and name.startswith("flow.b") and name.endswith((".fc1.w", ".fc2.w"))
+    return scheme == 0 and flow_dim % 256 == 0 and name.startswith("flow.b") and name.endswith((".fc1.w", ".fc2.w"))
 
 
-def int8_model(weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+def int8_model(weights: Dict[str, np.ndarray], scheme: int = 0) -> Dict[str, np.ndarray]:
     """Weight set for checking the int8 engine: like bf16_model, except that the matrices the engine quantises
-    to int8 stay float32 here (both sides derive the int8 values and scales from the same float32 numbers)."""
+    to int8 stay float32 here (both sides derive the int8 values and scales from the same float32 numbers).
+    scheme = Spec.q8_act_scheme of the pack the weights go into."""
     flow_dim = weights["flow.in_proj.w"].shape[0]
-    q = bf16_model(weights, two_term=TWO_TERM_DEFAULT[:3] if flow_dim % 256 == 0 else TWO_TERM_DEFAULT)
+    blocks_q8 = scheme == 0 and flow_dim % 256 == 0
+    q = bf16_model(weights, two_term=TWO_TERM_DEFAULT[:3] if blocks_q8 else TWO_TERM_DEFAULT)
     for k, v in weights.items():
-        if is_int8_weight(k, flow_dim):
+        if is_int8_weight(k, flow_dim, scheme):
             q[k] = v
     return q
 

@@ -7,7 +7,10 @@ apply that scheme to any subset of the six families and to either side alone (we
 row below is the float32 model with ONE such quantity quantised, against the float32 model, per-frame latents on the same
 history (the inputs of tests/test_gpu_configs.py::test_scaled_pack_int8_vs_float32_oracle).
 
-    python tools/int8_attribution.py [--scaled 0|1] [--out profiles/r03_int8_attribution.txt]
+    python tools/int8_attribution.py [--scaled 0|1] [--act block|dyn] [--out profiles/r03_int8_attribution.txt]
+
+--act dyn: the second activation scheme (per row, uint8 with a zero point over the whole row, as ONNX
+DynamicQuantizeLinear does it; LM layers only, the flow blocks stay bf16 in that scheme).
 """
 import argparse
 import ctypes as C
@@ -48,13 +51,19 @@ def main():
     ap.add_argument("--scaled", type=int, default=1)
     ap.add_argument("--out", default="")
     ap.add_argument("--frames", type=int, default=5)
+    ap.add_argument("--act", choices=["block", "dyn"], default="block")
     a = ap.parse_args()
     oracle_py.build()
     L = oracle_py.lib()
     L.ptts_oracle_enable_q8_some.argtypes = [C.c_void_p, C.c_int]
     L.ptts_oracle_set_q8_parts.argtypes = [C.c_int]
     L.ptts_oracle_set_lm_kv_bf16.argtypes = [C.c_int]
+    L.ptts_oracle_set_q8_act.argtypes = [C.c_int]
+    dyn = a.act == "dyn"
     spec = pp.Spec.full()
+    if dyn:
+        import dataclasses
+        spec = dataclasses.replace(spec, q8_act_scheme=1)
     kw = dict(residual_gain=1.0 / np.sqrt(2.0 * spec.lm_layers), gate_gain=0.25) if a.scaled else {}
     w = pp.synth_weights(spec, seed=1234, eos_bias=-20.0, **kw)
     rng = np.random.default_rng(77)
@@ -65,12 +74,14 @@ def main():
     path = os.path.join(tmp, "f32.ptts")
     pp.write_pack(path, spec, w)
     path_e = os.path.join(tmp, "engine.ptts")
-    pp.write_pack(path_e, spec, pp.int8_model(w))   # what the int8 engine holds beside its int8 matrices
+    pp.write_pack(path_e, spec, pp.int8_model(w, scheme=spec.q8_act_scheme))   # what the int8 engine holds beside its int8 matrices
 
     def run(pack, mask, parts, kv=False, base=None):
         o = oracle_py.Oracle(pack)
         if mask:
+            L.ptts_oracle_set_q8_act(1 if dyn else 0)
             L.ptts_oracle_enable_q8_some(o.h, mask)
+            L.ptts_oracle_set_q8_act(0)
         L.ptts_oracle_set_q8_parts(parts)
         L.ptts_oracle_set_lm_kv_bf16(1 if kv else 0)
         res = [frames_of(o, ids[i], voices[i], None if base is None else base[i][0], F, lsd) for i in range(3)]
@@ -94,15 +105,24 @@ def main():
            f"# each row: the float32 model with the named quantity in the engine's int8 scheme, against the float32 model")
     print(hdr)
     lines.append(hdr)
-    for name, bit in BITS.items():
-        report(f"{name}: int8 weight rows only", run(path, bit, 1, base=base))
-        report(f"{name}: int8 activation blocks only", run(path, bit, 2, base=base))
-    report("all six families: int8 weight rows only", run(path, 63, 1, base=base))
-    report("all six families: int8 activation blocks only", run(path, 63, 2, base=base))
-    report("all six families: weights and activations", run(path, 63, 3, base=base))
-    report("LM families only (flow blocks float32): both sides", run(path, 15, 3, base=base))
-    report("flow blocks only (LM float32): both sides", run(path, 48, 3, base=base))
-    report("the int8 engine's whole model (+ bf16 rest, bf16 K/V)", run(path_e, 63, 3, kv=True, base=base))
+    if dyn:
+        lines[-1] += "\n# activation scheme: per row, uint8 with one scale and zero point over the whole row (LM layers only)"
+        for name, bit in list(BITS.items())[:4]:
+            report(f"{name}: uint8 activation rows only", run(path, bit, 2, base=base))
+        report("LM families: int8 weight rows only", run(path, 15, 1, base=base))
+        report("LM families: uint8 activation rows only", run(path, 15, 2, base=base))
+        report("LM families: weights and activations", run(path, 15, 3, base=base))
+        report("the int8 engine's whole model (+ bf16 rest, bf16 K/V)", run(path_e, 15, 3, kv=True, base=base))
+    else:
+        for name, bit in BITS.items():
+            report(f"{name}: int8 weight rows only", run(path, bit, 1, base=base))
+            report(f"{name}: int8 activation blocks only", run(path, bit, 2, base=base))
+        report("all six families: int8 weight rows only", run(path, 63, 1, base=base))
+        report("all six families: int8 activation blocks only", run(path, 63, 2, base=base))
+        report("all six families: weights and activations", run(path, 63, 3, base=base))
+        report("LM families only (flow blocks float32): both sides", run(path, 15, 3, base=base))
+        report("flow blocks only (LM float32): both sides", run(path, 48, 3, base=base))
+        report("the int8 engine's whole model (+ bf16 rest, bf16 K/V)", run(path_e, 63, 3, kv=True, base=base))
     if a.out:
         with open(a.out, "w") as f:
             f.write("\n".join(lines) + "\n")

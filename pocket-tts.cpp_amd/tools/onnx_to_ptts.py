@@ -26,6 +26,11 @@ they are — int8 values (q - zero_point) and one scale per output row, next to 
 triplet allows it: scale per tensor or per output channel, q - zero_point within int8.  The int8 engine then multiplies
 with the source's own integers; other triplets are only dequantised.
 
+How the int8 engine quantises ACTIVATIONS is a field of the pack header (`q8_act_scheme`).  A graph file that holds
+DynamicQuantizeLinear / MatMulInteger nodes quantises every MatMul input per call as uint8 with one scale and one zero
+point; when an LM-layer matrix comes from such a file the pack is written with `q8_act_scheme` = 1 and the engine does
+the same per row (flow blocks then stay bf16 and are not carried as int8).  `"q8_act_scheme"` in the map's "spec" overrides.
+
 `--list` prints every tensor (name, type, shape) and, for MatMul / Gemm / Conv / ConvTranspose / Gather nodes, which
 initializer each consumes: the raw material for writing the map.  `--auto` maps by equal names (files whose
 initializers are already named like pack tensors), transposing 2-D tensors whose shape is the reverse of the pack's.
@@ -42,6 +47,7 @@ flow_lm_flow `c`, `s`, `t`, `x` -> `flow_dir` (:439-440); mimi_decoder `latent`,
 (:483, :534-536).  GRAPH_IO below holds them.
 """
 import argparse
+import dataclasses
 import json
 import os
 import sys
@@ -249,9 +255,14 @@ def convert(models_dir, out_path, map_path=None, auto=False, spec_over=None):
     if missing:
         raise SystemExit(f"{len(missing)} pack tensors have no source, e.g. {missing[:8]}; add them to the map (see --list)")
     weights = {name: fetch(files, tensors[name], shape) for name, shape, _ in table}
+    if "q8_act_scheme" not in spec_kw:
+        dynamic = {fn for fn, ow in files.items() if any(op in ("DynamicQuantizeLinear", "MatMulInteger") for op, _, _ in ow.nodes())}
+        lm_sources = {tensors[name].get("file") for name, _, _ in table if name.startswith("lm.l") and pp.is_int8_weight(name, spec.flow_dim)}
+        if dynamic & lm_sources:
+            spec = dataclasses.replace(spec, q8_act_scheme=1)
     q8 = {}
     for name, shape, _ in table:
-        if pp.is_int8_weight(name, spec.flow_dim):
+        if pp.is_int8_weight(name, spec.flow_dim, spec.q8_act_scheme):
             got = fetch_q8(files, tensors[name], shape)
             if got is not None:
                 q8[name] = got

@@ -178,6 +178,61 @@ def test_converter_round_trip(tmp_path, packs, ponnx):
         onnx_to_ptts.convert(str(mdir), out, str(tmp_path / "map2.json"))
 
 
+def test_converter_reads_the_activation_scheme_off_the_graph(tmp_path, packs, ponnx):
+    """An LM graph with DynamicQuantizeLinear + MatMulInteger nodes in front of its int8 matrices (what ONNX Runtime's
+    dynamic quantisation writes) gives a pack whose header asks the int8 engine for per-row uint8 activations; the flow
+    blocks, int8 in the file too, are then only dequantised.  Without those nodes, or with the field given in the map,
+    the header keeps what the map says."""
+    import onnx_to_ptts
+    import ptts_pack as pp
+    import dataclasses
+    spec = dataclasses.replace(pp.Spec.tiny(), flow_dim=256)     # wide enough for int8 flow blocks
+    w = pp.synth_weights(spec, seed=5)
+    spec_kw = {f: getattr(spec, f) for f in pp.SPEC_INT_FIELDS + pp.SPEC_FLOAT_FIELDS if f != "q8_act_scheme"}
+
+    def export(tag, with_nodes):
+        mdir = tmp_path / tag
+        mdir.mkdir()
+        per_file, nodes, mapping = {}, {}, {}
+        for k, (name, shape, _) in enumerate(pp.tensor_table(spec)):
+            a = w[name]
+            fn = _graph_of(name)
+            ent = {"file": fn, "tensor": f"t{k}"}
+            if pp.is_int8_weight(name, spec.flow_dim):
+                q, sc, z = ow.quantize_per_axis(np.ascontiguousarray(a.T), 1)
+                per_file.setdefault(fn, []).extend([ow.tensor(f"t{k}_quantized", q), ow.tensor(f"t{k}_scale", sc), ow.tensor(f"t{k}_zero_point", z)])
+                ent.update(transpose=True, axis=1)
+                if with_nodes:
+                    nodes.setdefault(fn, []).extend([
+                        ow.node("DynamicQuantizeLinear", [f"x{k}"], [f"x{k}_q", f"x{k}_s", f"x{k}_z"]),
+                        ow.node("MatMulInteger", [f"x{k}_q", f"t{k}_quantized", f"x{k}_z", f"t{k}_zero_point"], [f"y{k}_i"])])
+            elif a.ndim == 2 and name.endswith(".w") and name.startswith(("lm.", "flow.")):
+                per_file.setdefault(fn, []).append(ow.tensor(f"t{k}", np.ascontiguousarray(a.T)))
+                ent["transpose"] = True
+            elif name in ("dec.conv0.w", "enc.conv0.w"):
+                per_file.setdefault(fn, []).append(ow.tensor(f"t{k}", np.ascontiguousarray(a.reshape(a.shape[0], spec.kernel, -1).transpose(0, 2, 1))))
+                ent["conv"] = True
+            else:
+                per_file.setdefault(fn, []).append(ow.tensor(f"t{k}", a))
+            mapping[name] = ent
+        for fn, inits in per_file.items():
+            (mdir / fn).write_bytes(ow.model(inits, nodes.get(fn, ())))
+        return str(mdir), mapping
+
+    lm_q8 = sorted(n for n, _, _ in pp.tensor_table(spec) if n.startswith("lm.l") and pp.is_int8_weight(n, spec.flow_dim))
+    all_q8 = sorted(n for n, _, _ in pp.tensor_table(spec) if pp.is_int8_weight(n, spec.flow_dim))
+    assert len(all_q8) > len(lm_q8) > 0
+    out = str(tmp_path / "out.ptts")
+    for tag, with_nodes, over, scheme, carried in [("dyn", True, {}, 1, lm_q8), ("plain", False, {}, 0, all_q8),
+                                                   ("forced", True, {"q8_act_scheme": 0}, 0, all_q8)]:
+        mdir, mapping = export(tag, with_nodes)
+        mp = tmp_path / f"{tag}.json"
+        mp.write_text(json.dumps({"spec": dict(spec_kw, **over), "tensors": mapping}))
+        got_spec, _ = onnx_to_ptts.convert(mdir, out, str(mp))
+        assert got_spec.q8_act_scheme == scheme == pp.read_pack(out)[0].q8_act_scheme, tag
+        assert sorted(pp.read_pack_q8(out)) == carried, tag
+
+
 def test_converter_auto_map(tmp_path, packs, ponnx):
     """Files whose initializers carry the pack's own names convert without a map (2-D matrices may be transposed)."""
     import onnx_to_ptts

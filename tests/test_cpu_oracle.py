@@ -128,6 +128,59 @@ def test_oracle_int8_mode_is_quantisation_noise_away(packs, oracle_mod):
     np.testing.assert_array_equal(cond_of(of2), cf)
 
 
+def test_oracle_dynamic_uint8_product_follows_the_onnx_operators(oracle_mod):
+    """The checker's second int8 activation scheme against the operator definitions written out in numpy: identical
+    integers, so the results agree to the last float32 rounding of the one scaling multiply.  Rows cover: mixed sign,
+    all positive (zero point 0), all negative (zero point 255), all zero (scale 0), one huge outlier."""
+    import q8_schemes
+    rng = np.random.default_rng(3)
+    for (M, K, N) in [(7, 128, 48), (3, 1024, 64), (16, 256, 32)]:
+        A = (rng.standard_normal((M, K)) * rng.uniform(0.1, 3.0, (M, 1))).astype(np.float32)
+        A[0] = np.abs(A[0])
+        A[1] = -np.abs(A[1])
+        A[2] = 0.0
+        if M > 3:
+            A[3, 5] = 250.0
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        want, q, zp, s = q8_schemes.dynamic_uint8_product(A, W)
+        assert zp[0] == 0 and zp[1] == 255 and s[2] == 0 and q.min() >= 0 and q.max() <= 255
+        got = oracle_mod.q8_linear(A, W, scheme=1)
+        assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), (M, K, N)
+        assert np.all(got[2] == 0)
+        # and it is a different scheme from the per-block one: same weights, other activation grid
+        blk = oracle_mod.q8_linear(A, W, scheme=0)
+        exact = A.astype(np.float64) @ W.astype(np.float64).T
+        assert np.abs(blk - got).max() > 0
+        assert np.abs(got - exact).max() < 0.05 * np.abs(exact).max() and np.abs(blk - exact).max() < 0.05 * np.abs(exact).max()
+
+
+def test_oracle_int8_scheme_comes_from_the_pack_header(packs, oracle_mod, tmp_path):
+    """A pack whose header says q8_act_scheme = 1 makes the int8 checker use the dynamic uint8 activations (LM layers
+    only; the flow blocks stay bf16 there), a header of 0 the per-block scheme; two such objects live side by side."""
+    path, spec, w = packs["tiny"]
+    import dataclasses
+    import ptts_pack as pp
+    spec1 = dataclasses.replace(spec, q8_act_scheme=1)
+    p1 = str(tmp_path / "dyn.ptts")
+    pp.write_pack(p1, spec1, w)
+    assert pp.read_pack(p1)[0].q8_act_scheme == 1 and pp.read_pack(path)[0].q8_act_scheme == 0
+    of, o0, o1 = oracle_mod.Oracle(path), oracle_mod.Oracle(path, int8=True), oracle_mod.Oracle(p1, int8=True)
+    rng = np.random.default_rng(19)
+    emb = (rng.standard_normal((6, spec.d_model)) * 0.5).astype(np.float32)
+    seq = np.full((1, spec.latent_dim), np.nan, np.float32)
+
+    def cond_of(o):
+        st = o.lm_state(32)
+        o.lm_main(st, None, emb)
+        return o.lm_main(st, seq, None)[0]
+
+    cf, c0, c1 = cond_of(of), cond_of(o0), cond_of(o1)
+    assert np.abs(c0 - c1).max() > 1e-5
+    for c in (c0, c1):
+        assert 1e-4 < np.abs(cf - c).max() < 0.05 * np.abs(cf).max() + 0.05
+    np.testing.assert_array_equal(cond_of(o0), c0)   # creating the other object did not change this one's scheme
+
+
 # ----------------------------------------------------------------------------- multi-rank host logic
 
 def test_partition_is_balanced_and_deterministic():

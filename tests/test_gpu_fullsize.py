@@ -165,8 +165,9 @@ def test_full_int8_graphs_and_offline_parity(full):
     # correct implementations therefore agree only to that noise floor; the kernel arithmetic itself is checked
     # exactly in test_int8_product_is_exact.  The bounds below are regression guards at a few times that floor
     # (and "never further from the int8 oracle than int8 is from float"), NOT the 2e-2 the int8 engine is specified
-    # to against the float32 model: that bound is kept, unwidened and as an expected failure (1.5e-1 measured here,
-    # 8.3e-2 on the residual-scaled pack), in tests/test_gpu_configs.py.
+    # to against the float32 model: that bound is kept, unwidened and as an expected failure (1.5e-1 measured here;
+    # the residual-scaled pack and the share of each matrix family are in profiles/r03_int8_attribution.txt), in
+    # tests/test_gpu_configs.py.
     assert e_flow <= 5e-2 and e_lm <= 1.5e-1
     assert worst <= 1.5 * worst_f and worst <= 3e-1
     eng.close()
@@ -230,6 +231,95 @@ def test_int8_product_is_exact(full):
         got = eng.q8_linear(A, W)
         assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), (M, K, N)
     eng.close()
+
+
+def test_int8_dynamic_uint8_product_is_exact(full, oracle_mod):
+    """The second int8 activation scheme (rows as uint8 with one scale and zero point over the whole row, as ONNX
+    DynamicQuantizeLinear + MatMulInteger do it) against the operator definitions in numpy and against the checker:
+    the integer sums are identical, only the one float32 scaling multiply can differ in its last bit.  Rows cover all
+    positive, all negative, all zero and an outlier; shapes cover ragged row counts and the LM's three K / N pairs."""
+    import q8_schemes
+    eng = full["lib"].Engine(full["path"], precision="int8", temperature=0.0, lsd_steps=1, max_frames=1)
+    rng = np.random.default_rng(12)
+    for (M, K, N) in [(64, 1024, 3072), (5, 256, 64), (70, 4096, 1024), (1, 1024, 4096)]:
+        A = (rng.standard_normal((M, K)) * rng.uniform(0.1, 3.0, (M, 1))).astype(np.float32)
+        A[0] = np.abs(A[0])
+        if M > 4:
+            A[1] = -np.abs(A[1])
+            A[2] = 0.0
+            A[3, 5] = 250.0
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        want, _, zp, _ = q8_schemes.dynamic_uint8_product(A, W)
+        assert zp[0] == 0
+        got = eng.q8_linear(A, W, dynamic=True)
+        tol = 2e-6 * max(1.0, np.abs(want).max())
+        assert np.abs(got - want).max() <= tol, (M, K, N)
+        if M * K * N <= 70 * 4096 * 1024:
+            assert np.abs(got - oracle_mod.q8_linear(A, W, scheme=1)).max() <= tol, (M, K, N)
+    eng.close()
+
+
+def test_full_int8_dynamic_scheme_parity(full, oracle_mod, tmp_path):
+    """A pack whose header selects the dynamic uint8 activation scheme (what tools/onnx_to_ptts.py writes for a graph
+    that holds DynamicQuantizeLinear / MatMulInteger nodes): the int8 engine follows it (int8 LM layers with per-row
+    uint8 activations, bf16 flow blocks) and is compared with the checker in the same scheme, graph by graph and per frame,
+    and with the float32 checker.  POCKET_TTS_Q8_ACT=block on the same pack gives the per-block engine back."""
+    import dataclasses
+    import ptts_pack as pp
+    spec = dataclasses.replace(full["spec"], q8_act_scheme=1)
+    _, w = pp.read_pack(full["path"])
+    p_dyn, p_chk = str(tmp_path / "dyn.ptts"), str(tmp_path / "dyn_int8w.ptts")
+    pp.write_pack(p_dyn, spec, w)
+    pp.write_pack(p_chk, spec, pp.int8_model(w, scheme=1))
+    o8 = oracle_mod.Oracle(p_chk, int8=True)
+    eng = full["lib"].Engine(p_dyn, precision="int8", temperature=0.0, lsd_steps=10, max_frames=F)
+    rng = np.random.default_rng(5)
+    # LM: prefill + 3 decode steps on two slots (the decode products run split along K)
+    st = eng.state(2)
+    ost = [o8.lm_state(128), o8.lm_state(128)]
+    e_lm = 0.0
+    for slot in range(2):
+        emb = (rng.standard_normal((20 + 7 * slot, spec.d_model)) * 0.5).astype(np.float32)
+        eng.lm_prefill(st, slot, emb)
+        o8.lm_main(ost[slot], None, emb)
+    seq = np.full((2, spec.latent_dim), np.nan, np.float32)
+    for _ in range(3):
+        c, e = eng.lm_step(st, seq)
+        for slot in range(2):
+            oc, oe = o8.lm_main(ost[slot], seq[slot:slot + 1], None)
+            e_lm = max(e_lm, float(np.abs(c[slot] - oc).max()), abs(float(e[slot]) - float(oe)))
+        seq = (rng.standard_normal((2, spec.latent_dim)) * 0.7).astype(np.float32)
+    st.close()
+    # flow head: bf16 blocks in this scheme, so it is the bf16 engine's head
+    cond = rng.standard_normal((3, spec.d_model)).astype(np.float32)
+    x0 = (rng.standard_normal((3, spec.latent_dim)) * 0.8).astype(np.float32)
+    e_flow = float(np.abs(eng.flow_euler(cond, x0) - np.stack([o8.flow_euler(cond[i], x0[i], 10) for i in range(3)])).max())
+    res = eng.generate_ids(full["ids"], full["voices"])
+    worst = worst_f = 0.0
+    for i in range(3):
+        lat8, _, frames = oracle_replay(o8, full["ids"][i], full["voices"][i], res[i]["latents"], 10, F)
+        latf, _, _ = oracle_replay(full["o"], full["ids"][i], full["voices"][i], res[i]["latents"], 10, F)
+        assert res[i]["frames"] == frames == F
+        worst = max(worst, float(np.abs(res[i]["latents"] - lat8).max()))
+        worst_f = max(worst_f, float(np.abs(res[i]["latents"] - latf).max()))
+    eng.close()
+    os.environ["POCKET_TTS_Q8_ACT"] = "block"
+    try:
+        outs = []
+        for pth in (p_dyn, full["path"]):      # one engine at a time: only one holds the one-launch flow head
+            e2 = full["lib"].Engine(pth, precision="int8", temperature=0.0, lsd_steps=10, max_frames=F)
+            outs.append(e2.flow_euler(cond, x0))
+            e2.close()
+        a, b = outs
+    finally:
+        os.environ.pop("POCKET_TTS_Q8_ACT", None)
+    np.testing.assert_array_equal(a, b)
+    _note(f"int8 full size, dynamic uint8 activations: flow head (bf16 blocks) max-abs {e_flow:.3e}, LM cond/eos max-abs {e_lm:.3e}, "
+          f"per-frame latent max-abs vs int8 oracle {worst:.3e}, vs f32 oracle {worst_f:.3e}")
+    # As with the per-block scheme, a rounding that flips moves the quantised model by about 1e-2, so two correct
+    # implementations agree to that noise floor and not to float accuracy; the product itself is checked exactly above.
+    assert e_flow <= 2e-2 and e_lm <= 1.5e-1
+    assert worst <= 1.5 * worst_f and worst <= 3e-1
 
 
 def test_flow_head_persistent_form_matches_launch_chain(full):
