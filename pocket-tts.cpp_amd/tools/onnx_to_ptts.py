@@ -35,10 +35,13 @@ the same per row (flow blocks then stay bf16 and are not carried as int8).  `"q8
 initializer each consumes: the raw material for writing the map.  `--auto` maps by equal names (files whose
 initializers are already named like pack tensors), transposing 2-D tensors whose shape is the reverse of the pack's.
 `--guess OUT.json` writes a first draft of the map for files whose initializers carry exporter names: per graph file it
-walks the nodes in graph order and gives every pack tensor of that graph (in the pack's own layer order) the first unused
-initializer whose shape fits (as stored, transposed, or as a Conv1d weight); what it cannot place is listed under
-"unresolved".  The draft is for a person to review against `--list`: shapes repeat from layer to layer, and only the
-order of the graph tells them apart.
+walks the nodes in graph order and gives every pack tensor of that graph (in the pack's own layer order) the first use,
+not yet taken, of a tensor whose shape fits (as stored, transposed, or as a Conv1d weight).  The consuming node settles
+what shapes cannot: a MatMul's second input is [in][out] and is transposed even when square.  Separate q / k / v matrices
+become one "concat" entry, Constant-node tensors count like initializers, a tensor consumed by two nodes may serve two pack
+tensors ("shared_with").  Guesses the file does not settle carry a "note"; what cannot be placed is listed under
+"unresolved" with the shapes still free in that file.  The draft is for a person to review against `--list`: shapes
+repeat from layer to layer, and only the order of the graph tells them apart.
 
 What the reference itself pins are the names of the graphs' inputs and outputs, not of their weights:
 mimi_encoder `audio` -> `latents` (src/pocket_tts.cpp:266-267); text_conditioner `token_ids` -> `embeddings` (:305-306);
@@ -189,54 +192,106 @@ def auto_map(files, table):
     return tensors
 
 
-def guess_map(models_dir, spec, int8=False):
-    """First draft of a name map by shape and graph order; returns (tensors, unresolved)."""
-    files = open_all(models_dir)
-    order = {}
-    for fn, ow in files.items():
-        seq, seen = [], set()
+def consumption_order(ow):
+    """Every use of a weight tensor by a node, in graph order: (base name, stored shape, op type, input position), a
+    tensor consumed by two nodes appearing twice.  A Constant node's tensor carries its output name, so it is seen where
+    a later node consumes that name.  Tensors that no node consumes follow in file order (op None)."""
+    def base_of(nm):
+        if nm.endswith(("_scale", "_zero_point")):
+            return None
+        base = nm[:-len("_quantized")] if nm.endswith("_quantized") else nm
+        key = base + "_quantized" if base + "_quantized" in ow.info else base
+        return (base, tuple(ow.info[key][2])) if key in ow.info else None
 
-        def add(nm):
-            base = nm[:-len("_quantized")] if nm.endswith("_quantized") else nm
-            if base in seen or nm.endswith(("_scale", "_zero_point")):
-                return
-            key = base + "_quantized" if base + "_quantized" in ow.info else base
-            if key in ow.info:
-                seen.add(base)
-                seq.append((base, tuple(ow.info[key][2])))
-        for _, ins, _ in ow.nodes():
-            for i in ins:
-                add(i)
-        for nm in ow.info:
-            add(nm)
-        order[fn] = seq
-    tensors, unresolved, used = {}, [], {fn: set() for fn in files}
+    events, seen = [], set()
+    for op, ins, _ in ow.nodes():
+        if op in ("DynamicQuantizeLinear", "Constant"):
+            continue
+        for pos, nm in enumerate(ins):
+            hit = base_of(nm)
+            if hit:
+                events.append((hit[0], hit[1], op, pos))
+                seen.add(hit[0])
+    for nm in ow.info:
+        hit = base_of(nm)
+        if hit and hit[0] not in seen:
+            seen.add(hit[0])
+            events.append((hit[0], hit[1], None, -1))
+    return events
+
+
+def guess_map(models_dir, spec, int8=False):
+    """First draft of a name map by shape and graph order; returns (tensors, unresolved).
+
+    Per graph file the pack's tensors are taken in the pack's own order and each gets the first use, not yet taken, of a
+    tensor whose shape fits.  What the shapes cannot tell, the consuming node does: the second input of a MatMul /
+    MatMulInteger is stored [in][out] and is transposed even when square.  A fused projection that the file holds as
+    separate matrices (q, k, v) is drafted as a "concat" of consecutive uses.  A tensor consumed by two nodes may serve two
+    pack tensors; the second entry says so ("shared_with").  Entries that rest on a guess the shapes do not settle carry a
+    "note"; what cannot be placed is listed under unresolved, with the shapes still free in that file."""
+    files = open_all(models_dir)
+    order = {fn: consumption_order(ow) for fn, ow in files.items()}
+    tensors, unresolved = {}, []
+    used = {fn: set() for fn in files}          # indices into order[fn]
+    owner = {fn: {} for fn in files}            # tensor name -> pack tensor that took it first
+    squeeze = lambda t: tuple(d for d in t if d != 1)
+
+    def fit(fn, ev, want):
+        """Map entry if this use can be the pack tensor of shape `want`, else None."""
+        base, have, op, pos = ev
+        ent = {"file": fn, "tensor": base, "guessed": True}
+        matmul_b = op in ("MatMul", "MatMulInteger") and pos == 1
+        if len(want) == 2 and len(have) == 2 and have[0] == have[1] == want[0] == want[1]:
+            if matmul_b:
+                ent["transpose"] = True
+            elif op not in ("Gemm",):
+                ent["note"] = "square matrix and no MatMul/Gemm consumer: stored orientation unknown"
+            return ent
+        if have == want or squeeze(have) == squeeze(want):
+            if matmul_b and len(want) == 2 and len(squeeze(want)) == 2:
+                return None                     # a MatMul weight stored [out][in] would not multiply: another tensor
+            return ent
+        if len(want) == 2 and len(have) == 2 and have == want[::-1]:
+            ent["transpose"] = True
+            return ent
+        if len(want) == 2 and len(have) == 3 and have[0] == want[0] and have[1] * have[2] == want[1]:
+            ent["conv"] = True
+            return ent
+        return None
+
+    def take(fn, idx, name, ent):
+        used[fn].add(idx)
+        first = owner[fn].setdefault(ent["tensor"], name)
+        if first != name:
+            ent["shared_with"] = first
+        return ent
+
     for name, shape, _ in pp.tensor_table(spec):
         fn = graph_file(name, int8)
         if fn not in files and int8:
             fn = graph_file(name, False)
         want = tuple(shape)
-        squeeze = lambda t: tuple(d for d in t if d != 1)
+        evs = order.get(fn, [])
         hit = None
-        for base, have in order.get(fn, []):
-            if base in used[fn]:
+        for idx, ev in enumerate(evs):
+            if idx in used[fn]:
                 continue
-            ent = {"file": fn, "tensor": base, "guessed": True}
-            if have == want or squeeze(have) == squeeze(want):
-                hit = ent
-            elif len(want) == 2 and len(have) == 2 and have == want[::-1]:
-                ent["transpose"] = True
-                hit = ent
-            elif len(want) == 2 and len(have) == 3 and have[0] == want[0] and have[1] * have[2] == want[1]:
-                ent["conv"] = True
-                hit = ent
-            if hit:
-                used[fn].add(base)
+            ent = fit(fn, ev, want)
+            if ent:
+                hit = take(fn, idx, name, ent)
                 break
+        if hit is None and len(want) == 2 and name.endswith(".qkv.w") and want[0] == 3 * want[1]:
+            # separate q / k / v projections: the next three free uses of a [D][D] matrix, in graph order
+            part = (want[1], want[1])
+            free = [(idx, ev) for idx, ev in enumerate(evs) if idx not in used[fn] and fit(fn, ev, part)]
+            if len(free) >= 3:
+                parts = [take(fn, idx, name, fit(fn, ev, part)) for idx, ev in free[:3]]
+                hit = {"concat": parts, "guessed": True, "note": "q, k, v taken as the next three free [D][D] matrices in graph order"}
         if hit:
             tensors[name] = hit
         else:
-            unresolved.append({"pack_tensor": name, "shape": list(want), "file": fn})
+            left = sorted({ev[1] for idx, ev in enumerate(evs) if idx not in used[fn]})
+            unresolved.append({"pack_tensor": name, "shape": list(want), "file": fn, "free_shapes_in_file": [list(t) for t in left][:12]})
     for ow in files.values():
         ow.close()
     return tensors, unresolved

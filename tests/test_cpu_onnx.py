@@ -257,34 +257,79 @@ def test_converter_auto_map(tmp_path, packs, ponnx):
         np.testing.assert_array_equal(w2[name], w[name], err_msg=name)
 
 
-def test_guess_map_by_shape_and_graph_order(tmp_path, packs, ponnx):
-    """Exporter-style files: opaque initializer names, one node per tensor in the model's own layer order, matrices stored
-    [in][out], conv weights [Cout][Cin][k].  The draft map places every tensor, and the pack built from it is the model."""
+def _exporter_files(mdir, spec, w, drop=None):
+    """Writes the five graphs the way an exporter would: opaque names, initializers in another order than the nodes,
+    every Linear matrix stored [in][out] behind a MatMul (square ones too), the LM layers' fused qkv as three separate
+    MatMuls, the Mimi transformers' matrices as Constant nodes, conv weights [Cout][Cin][k] behind a Conv, and one norm
+    gain stored once but consumed by the two layers that share its values.  Returns {pack tensor: stored names}."""
     import onnx_to_ptts
     import ptts_pack as pp
-    path, spec, w = packs["tiny"]
-    mdir = tmp_path / "onnx"
-    mdir.mkdir()
-    per_file, nodes = {}, {}
+    per_file, nodes, stored = {}, {}, {}
+    rng = np.random.default_rng(0)
+    D = spec.d_model
     for k, (name, shape, _) in enumerate(pp.tensor_table(spec)):
         a = w[name]
         fn = onnx_to_ptts.graph_file(name)
-        tname = f"onnx::T_{7000 + 3 * k}"
-        if a.ndim == 2 and name.endswith(".w") and name.startswith(("lm.", "flow.")) and a.shape[0] != a.shape[1]:
-            a = np.ascontiguousarray(a.T)
-            op = "MatMul"
+        inits, nds = per_file.setdefault(fn, []), nodes.setdefault(fn, [])
+        t = f"onnx::T_{7000 + 3 * k}"
+        linear = a.ndim == 2 and name.endswith(".w") and (name.startswith(("lm.", "flow.")) or ".t" in name)
+        if name == drop:
+            continue
+        if name == "lm.l1.ln1.g":                                   # same values as layer 0's: the file holds one tensor
+            nds.append(ow.node("Mul", [f"act_{k}", stored["lm.l0.ln1.g"][0]], [f"act_{k + 1}"]))
+            stored[name] = stored["lm.l0.ln1.g"]
+        elif name.startswith("lm.l") and name.endswith(".qkv.w"):
+            names = []
+            for part in range(3):
+                tp = f"{t}_{part}"
+                inits.append(ow.tensor(tp, np.ascontiguousarray(a[part * D:(part + 1) * D].T)))
+                nds.append(ow.node("MatMul", [f"act_{k}", tp], [f"act_{k}_{part}"]))
+                names.append(tp)
+            stored[name] = names
+        elif linear and ".t" in name:                               # Constant node: the tensor is named by the node's output
+            nds.append(ow.node("Constant", [], [t], const=ow.tensor("", np.ascontiguousarray(a.T))))
+            nds.append(ow.node("MatMul", [f"act_{k}", t], [f"act_{k + 1}"]))
+            stored[name] = [t]
+        elif linear:
+            inits.append(ow.tensor(t, np.ascontiguousarray(a.T)))
+            nds.append(ow.node("MatMul", [f"act_{k}", t], [f"act_{k + 1}"]))
+            stored[name] = [t]
         elif name in ("dec.conv0.w", "enc.conv0.w"):
-            a = np.ascontiguousarray(a.reshape(a.shape[0], spec.kernel, -1).transpose(0, 2, 1))
-            op = "Conv"
+            inits.append(ow.tensor(t, np.ascontiguousarray(a.reshape(a.shape[0], spec.kernel, -1).transpose(0, 2, 1))))
+            nds.append(ow.node("Conv", [f"act_{k}", t], [f"act_{k + 1}"]))
+            stored[name] = [t]
         else:
-            op = "MatMul" if a.ndim == 2 else "Add"
-        per_file.setdefault(fn, []).append(ow.tensor(tname, a))
-        nodes.setdefault(fn, []).append(ow.node(op, [f"act_{k}", tname], [f"act_{k + 1}"]))
+            inits.append(ow.tensor(t, a))
+            nds.append(ow.node("Conv" if a.ndim == 2 else "Add", [f"act_{k}", t], [f"act_{k + 1}"]))
+            stored[name] = [t]
     for fn in per_file:
-        (mdir / fn).write_bytes(ow.model(per_file[fn][::-1], nodes[fn]))     # initializers stored in another order than the nodes
+        inits = per_file[fn]
+        (mdir / fn).write_bytes(ow.model([inits[i] for i in rng.permutation(len(inits))], nodes[fn]))
+    return stored
+
+
+def test_guess_map_by_shape_and_graph_order(tmp_path, packs, ponnx):
+    """The draft map for exporter-style files (see _exporter_files) places every tensor, and the pack built from it is the
+    model: the order of the nodes, not of the initializers, tells layers apart; a MatMul's weight is transposed even when
+    square; separate q / k / v become one concat entry; Constant-node tensors are found; a tensor consumed twice serves
+    two pack tensors and the draft says so."""
+    import onnx_to_ptts
+    import ptts_pack as pp
+    path, spec, w = packs["tiny"]
+    w = dict(w)
+    w["lm.l1.ln1.g"] = w["lm.l0.ln1.g"].copy()
+    mdir = tmp_path / "onnx"
+    mdir.mkdir()
+    stored = _exporter_files(mdir, spec, w)
     spec_kw = {f: getattr(spec, f) for f in pp.SPEC_INT_FIELDS + pp.SPEC_FLOAT_FIELDS}
     tensors, unresolved = onnx_to_ptts.guess_map(str(mdir), pp.Spec(**spec_kw))
     assert not unresolved and len(tensors) == len(pp.tensor_table(spec))
+    for name, names in stored.items():
+        ent = tensors[name]
+        got = [e["tensor"] for e in ent["concat"]] if "concat" in ent else [ent["tensor"]]
+        assert got == names, name
+    assert tensors["lm.l1.ln1.g"]["shared_with"] == "lm.l0.ln1.g" and "shared_with" not in tensors["lm.l0.ln1.g"]
+    assert all(e.get("transpose") for e in tensors["lm.l0.qkv.w"]["concat"]) and tensors["lm.l0.out.w"].get("transpose")
     (tmp_path / "draft.json").write_text(json.dumps({"spec": spec_kw, "tensors": tensors}))
     out = str(tmp_path / "guessed.ptts")
     onnx_to_ptts.convert(str(mdir), out, str(tmp_path / "draft.json"))
@@ -292,3 +337,22 @@ def test_guess_map_by_shape_and_graph_order(tmp_path, packs, ponnx):
     for name in w:
         np.testing.assert_array_equal(w2[name], w[name], err_msg=name)
     assert set(onnx_to_ptts.GRAPH_IO) == {"mimi_encoder", "text_conditioner", "flow_lm_main", "flow_lm_flow", "mimi_decoder"}
+
+
+def test_guess_map_lists_what_it_cannot_place(tmp_path, packs, ponnx):
+    """A file that lacks a tensor: the draft does not invent one.  The last pack tensor of that shape stays unresolved,
+    with the shapes still free in the file beside it, and files that are complete are placed in full."""
+    import onnx_to_ptts
+    import ptts_pack as pp
+    path, spec, w = packs["tiny"]
+    w = dict(w)
+    w["lm.l1.ln1.g"] = w["lm.l0.ln1.g"].copy()
+    mdir = tmp_path / "onnx"
+    mdir.mkdir()
+    _exporter_files(mdir, spec, w, drop="flow.b1.fc2.w")
+    tensors, unresolved = onnx_to_ptts.guess_map(str(mdir), spec)
+    assert len(unresolved) == 1 and len(tensors) == len(pp.tensor_table(spec)) - 1
+    u = unresolved[0]
+    assert u["file"] == "flow_lm_flow.onnx" and u["shape"] == [spec.flow_dim, spec.flow_dim] and u["pack_tensor"].startswith("flow.")
+    assert [spec.flow_dim, spec.flow_dim] not in u["free_shapes_in_file"]
+    assert all(n in tensors for n, _, _ in pp.tensor_table(spec) if not n.startswith("flow."))
