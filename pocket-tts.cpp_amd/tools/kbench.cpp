@@ -133,7 +133,10 @@ static void bench_gemm(const char* name, int M, int N, int K, int split_a, int l
     g.W = bf16_weight(N, K); g.wtype = W_BF16;
     g.C = (float*)dalloc((size_t)M * N * 4, 0); g.ldc = N;
     g.M = M; g.N = N; g.K = K; g.split_a = split_a;
-    time_it(name, 50, [&](hipStream_t s) { launch_gemm(g, s); }, (double)N * K * 2 + (double)M * lda * 4 + (double)M * N * 4, 2.0 * M * N * K);
+    // KB_GEMM_ABF / KB_GEMM_CBF: rows in / out as bf16, as the decoder's late stages and transformer hold them
+    const int abf = !split_a && std::getenv("KB_GEMM_ABF") ? 1 : 0, cbf = !split_a && std::getenv("KB_GEMM_CBF") ? 1 : 0;
+    g.a_bf16 = abf; g.c_bf16 = cbf;
+    time_it(name, 50, [&](hipStream_t s) { launch_gemm(g, s); }, (double)N * K * 2 + (double)M * lda * (abf ? 2 : 4) + (double)M * N * (cbf ? 2 : 4), 2.0 * M * N * K);
 }
 
 
