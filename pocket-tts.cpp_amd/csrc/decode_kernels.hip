@@ -325,15 +325,23 @@ __global__ __launch_bounds__(256) void skinny_q8o_kernel(SkinnyArgs a) {
     const int KS_total = a.K / KSTEP;
     const uint4* wbase = (const uint4*)a.Wp + (long long)nt * KS_total * 64 + lane;
 
-    // ---- row statistics over the full K: wave w takes rows w, w + 4, ...
+    // ---- row statistics over the full K: wave w takes rows w, w + 4, ...  (from the producers' partial ranges when given)
     for (int rr = wave; rr < ROWS; rr += 4) {
         float lo = 0.f, hi = 0.f;
         if (m0 + rr < a.M) {
-            const float* ar = a.A + (long long)(m0 + rr) * a.lda;
-            for (int k = 4 * lane; k < a.K; k += 256) {
-                const float4 v = *(const float4*)(ar + k);
-                lo = fminf(lo, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
-                hi = fmaxf(hi, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            if (a.a_mm) {
+                for (int p = lane; p < a.mm_parts; p += 64) {
+                    const float2 mm = *(const float2*)(a.a_mm + ((long long)p * a.M + m0 + rr) * 2);
+                    lo = fminf(lo, mm.x);
+                    hi = fmaxf(hi, mm.y);
+                }
+            } else {
+                const float* ar = a.A + (long long)(m0 + rr) * a.lda;
+                for (int k = 4 * lane; k < a.K; k += 256) {
+                    const float4 v = *(const float4*)(ar + k);
+                    lo = fminf(lo, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+                    hi = fmaxf(hi, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+                }
             }
         }
 #pragma unroll
@@ -407,10 +415,15 @@ __global__ __launch_bounds__(256) void skinny_q8o_kernel(SkinnyArgs a) {
             }
         }
     }
-    if (!tile_live) return;
+    if (!tile_live) return;   // (launches that ask for c_mm have N % 64 == 0: no dead tile in front of the barriers below)
     const int col = nt * 16 + r;
     const float ws = a.wscale[col];
     const int wsum = a.wsum[(long long)blockIdx.y * a.N + col];
+    float outv[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) outv[mt][i] = 0.f;   // rows past M: 0 is inside every range
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -423,9 +436,33 @@ __global__ __launch_bounds__(256) void skinny_q8o_kernel(SkinnyArgs a) {
                 a.P[((long long)blockIdx.y * a.M + row) * a.N + col] = v;
             } else {
                 if (a.bias) v = __fadd_rn(v, a.bias[col]);
-                a.C[(long long)row * a.ldc + col] = act_dev(v, a.act);
+                v = act_dev(v, a.act);
+                a.C[(long long)row * a.ldc + col] = v;
+                outv[mt][i] = v;
             }
         }
+    }
+    if (!a.c_mm) return;
+    // ranges of the result rows over this workgroup's 64 columns: 16 columns per wave by DPP-row shuffles, 4 waves through LDS
+    // (the staging buffer is free: every wave is past its last MFMA only after the barrier below)
+    __syncthreads();
+    float* red = (float*)As;   // [4 waves][ROWS][2]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float lo = outv[mt][i], hi = outv[mt][i];
+#pragma unroll
+            for (int of = 1; of < 16; of <<= 1) { lo = fminf(lo, __shfl_xor(lo, of, 64)); hi = fmaxf(hi, __shfl_xor(hi, of, 64)); }
+            if (r == 0) { red[(wave * ROWS + mt * 16 + g * 4 + i) * 2] = lo; red[(wave * ROWS + mt * 16 + g * 4 + i) * 2 + 1] = hi; }
+        }
+    }
+    __syncthreads();
+    if (tid < ROWS && m0 + tid < a.M) {
+        float lo = red[tid * 2], hi = red[tid * 2 + 1];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { lo = fminf(lo, red[(w * ROWS + tid) * 2]); hi = fmaxf(hi, red[(w * ROWS + tid) * 2 + 1]); }
+        *(float2*)(a.c_mm + ((long long)blockIdx.x * a.M + m0 + tid) * 2) = make_float2(lo, hi);
     }
 }
 
@@ -835,6 +872,8 @@ void launch_skinny_gemm(const SkinnyArgs& a, hipStream_t s) {
     if (a.wtype == W_I8 && a.q8_act == 1) {
         if (!a.wsum) throw std::runtime_error("skinny gemm: the dynamic uint8 activation scheme needs the weight row sums");
         if (a.lda % 4 || a.K % 4) throw std::runtime_error("skinny gemm: rows must be 16-byte aligned for the dynamic uint8 scheme");
+        if (a.a_mm && a.mm_parts < 1) throw std::runtime_error("skinny gemm: row ranges need their part count");
+        if (a.c_mm && (a.P || a.N % 64)) throw std::runtime_error("skinny gemm: result ranges go with the C form and N % 64 == 0");
         if (mt == 1) hipLaunchKernelGGL(skinny_q8o_kernel<1>, grid, block, 0, s, a);
         else if (mt == 2) hipLaunchKernelGGL(skinny_q8o_kernel<2>, grid, block, 0, s, a);
         else hipLaunchKernelGGL(skinny_q8o_kernel<4>, grid, block, 0, s, a);
@@ -980,6 +1019,17 @@ __global__ __launch_bounds__(256) void add_norm_kernel(AddNormArgs a) {
             *(unsigned*)(a.Hq + (long long)m * a.D + c) = quantize4(y4, inv);
             if ((tid & 15) == 0) a.Hd[(long long)(c >> 6) * a.Mq + m] = bm / 127.0f;
         }
+    }
+    if (a.H_mm) {
+        // the row's range: lanes past the row hold 0, which the consumer includes anyway
+        float lo = on ? fminf(fminf(y0, y1), fminf(y2, y3)) : 0.f, hi = on ? fmaxf(fmaxf(y0, y1), fmaxf(y2, y3)) : 0.f;
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) { lo = fminf(lo, __shfl_xor(lo, of, 64)); hi = fmaxf(hi, __shfl_xor(hi, of, 64)); }
+        __shared__ float mm[8];
+        if ((tid & 63) == 0) { mm[(tid >> 6) * 2] = lo; mm[(tid >> 6) * 2 + 1] = hi; }
+        __syncthreads();
+        if (tid == 0)
+            *(float2*)(a.H_mm + (long long)m * 2) = make_float2(fminf(fminf(mm[0], mm[2]), fminf(mm[4], mm[6])), fmaxf(fmaxf(mm[1], mm[3]), fmaxf(mm[5], mm[7])));
     }
     if (a.dot_w) {
         dot = block_sum4(dot, red, tid);
@@ -1243,6 +1293,12 @@ __global__ __launch_bounds__(256, 4) void attn_decode_kernel(AttnDecodeArgs a) {
         if (lane == 0) a.out_d[(long long)h * a.Mq + m] = bm / 127.0f;
     } else {
         a.out[(long long)m * a.d + h * 64 + lane] = out;
+    }
+    if (a.out_mm) {
+        float lo = out, hi = out;
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) { lo = fminf(lo, __shfl_xor(lo, of, 64)); hi = fmaxf(hi, __shfl_xor(hi, of, 64)); }
+        if (lane == 0) *(float2*)(a.out_mm + ((long long)h * a.M + m) * 2) = make_float2(lo, hi);
     }
 }
 

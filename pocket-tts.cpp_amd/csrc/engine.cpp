@@ -619,6 +619,10 @@ Batch::Batch(Engine& e, int B_, bool lm_only_) : B(B_), Bw(B_), lm_only(lm_only_
         zeroed(hq, static_cast<size_t>(B) * D); zeroed(hd, static_cast<size_t>(D / 64) * q_rows * 4);
         zeroed(attq, static_cast<size_t>(B) * D); zeroed(attd, static_cast<size_t>(s.lm_heads) * q_rows * 4);
         zeroed(ffq, static_cast<size_t>(B) * s.lm_ffn); zeroed(ffd, static_cast<size_t>(s.lm_ffn / 64) * q_rows * 4);
+        if (e.model().q8_act == 1) {
+            zeroed(mm_h, static_cast<size_t>(B) * 8); zeroed(mm_att, static_cast<size_t>(s.lm_heads) * B * 8);
+            zeroed(mm_ff, static_cast<size_t>(s.lm_ffn / 64) * B * 8);
+        }
     }
     for (auto& pair : tev)
         for (auto& ev : pair) PTTS_HIP(hipEventCreate(&ev));
@@ -1161,9 +1165,13 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
     // the FFN-1 epilogue), so the products read int8 rows and stage nothing
     // (block scheme only: in the dynamic uint8 scheme the products quantise their rows themselves)
     const bool preq = wt == W_I8 && model_->q8_act == 0 && b.q_rows > 0 && !std::getenv("POCKET_TTS_Q8_STAGED");
+    // dynamic uint8 scheme: the producers leave the (min, max) of the rows they write, so that the products need not scan
+    // their rows over the full K before quantising them (POCKET_TTS_Q8_STAGED=1: the products scan)
+    const bool dyn_mm = wt == W_I8 && model_->q8_act == 1 && b.mm_h.p && !std::getenv("POCKET_TTS_Q8_STAGED");
     AddNormArgs an;
     an.X = b.x.f(); an.ldx = D; an.M = B; an.D = D; an.eps = s.lm_eps;
     an.g = hd_.lm[0].ln1g; an.b = hd_.lm[0].ln1b; an.H = b.h.f();
+    if (dyn_mm) an.H_mm = b.mm_h.f();
     if (preq) { an.H = nullptr; an.Hq = b.hq.as<signed char>(); an.Hd = b.hd.f(); an.Mq = b.q_rows; }
     {
         AddNormArgs a0 = an;
@@ -1179,6 +1187,7 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         q.splits = s_qkv; q.P = b.qkv.f();   // K-slice slabs, summed where the attention kernel reads them
         if (preq) { q.A = nullptr; q.Aq = b.hq.as<signed char>(); q.ldaq = D; q.Ad = b.hd.f(); q.Mq = b.q_rows; }
         bind_q8_act(q, model_->q8_act, pw.ws_qkv);
+        if (dyn_mm) { q.a_mm = b.mm_h.f(); q.mm_parts = 1; }
         launch_skinny_gemm(q, b.st);
         AttnDecodeArgs at;
         const long long kv_off = static_cast<long long>(l) * layer_stride * (b.kv16 ? 2 : 4);
@@ -1187,11 +1196,13 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
         at.cos_tab = model_->lm_cos; at.sin_tab = model_->lm_sin; at.tab_len = model_->lm_tab_len;
         at.out = b.att.f();
         if (preq) { at.out = nullptr; at.out_q = b.attq.as<signed char>(); at.out_d = b.attd.f(); at.Mq = b.q_rows; }
+        if (dyn_mm) at.out_mm = b.mm_att.f();
         launch_attn_decode(at, b.st);
         SkinnyArgs o;
         o.A = b.att.f(); o.lda = D; o.Wp = pw.out; o.Wp2 = pw.out_lo; o.wtype = wt; o.wscale = pw.s_out; o.M = B; o.N = D; o.K = D; o.splits = s_out; o.P = b.partial.f();
         if (preq) { o.A = nullptr; o.Aq = b.attq.as<signed char>(); o.ldaq = D; o.Ad = b.attd.f(); o.Mq = b.q_rows; }
         bind_q8_act(o, model_->q8_act, pw.ws_out);
+        if (dyn_mm) { o.a_mm = b.mm_att.f(); o.mm_parts = s.lm_heads; }
         launch_skinny_gemm(o, b.st);
         AddNormArgs a1 = an;
         a1.P = b.partial.f(); a1.splits = s_out; a1.colscale = w.ls1; a1.g = w.ln2g; a1.b = w.ln2b;
@@ -1204,18 +1215,20 @@ void Engine::lm_step_dev(Batch& b, const float* seq_dev, float* cond_dev, float*
             f1.C = nullptr; f1.Cq = b.ffq.as<signed char>(); f1.Cd = b.ffd.f();
         }
         bind_q8_act(f1, model_->q8_act, pw.ws_ff1);
+        if (dyn_mm) { f1.a_mm = b.mm_h.f(); f1.mm_parts = 1; f1.c_mm = b.mm_ff.f(); }
         launch_skinny_gemm(f1, b.st);
         SkinnyArgs f2;
         f2.A = b.ff.f(); f2.lda = F; f2.Wp = pw.ff2; f2.Wp2 = pw.ff2_lo; f2.wtype = wt; f2.wscale = pw.s_ff2; f2.M = B; f2.N = D; f2.K = F; f2.splits = s_ff2; f2.P = b.partial.f();
         if (preq) { f2.A = nullptr; f2.Aq = b.ffq.as<signed char>(); f2.ldaq = F; f2.Ad = b.ffd.f(); f2.Mq = b.q_rows; }
         bind_q8_act(f2, model_->q8_act, pw.ws_ff2);
+        if (dyn_mm) { f2.a_mm = b.mm_ff.f(); f2.mm_parts = F / 64; }
         launch_skinny_gemm(f2, b.st);
         AddNormArgs a2 = an;
         a2.P = b.partial.f(); a2.splits = s_ff2; a2.colscale = w.ls2;
         if (l + 1 < s.lm_layers) {
             a2.g = hd_.lm[l + 1].ln1g; a2.b = hd_.lm[l + 1].ln1b;
         } else {
-            a2.g = hd_.out_g; a2.b = hd_.out_b; a2.H32 = cond_dev; a2.Hq = nullptr; a2.H = preq ? nullptr : a2.H;
+            a2.g = hd_.out_g; a2.b = hd_.out_b; a2.H32 = cond_dev; a2.Hq = nullptr; a2.H = preq ? nullptr : a2.H; a2.H_mm = nullptr;
             a2.dot_w = hd_.eos_w; a2.dot_b = hd_.eos_b; a2.dot_out = eos_dev;
             a2.pos = b.lm_pos.as<int>(); a2.pos_delta = 1;
         }

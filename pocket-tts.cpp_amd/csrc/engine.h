@@ -407,6 +407,7 @@ public:
     DevBuf partial;   // split-K slabs of the decode step [splits][B][d_model] f32
     DevBuf hq, hd, attq, attd, ffq, ffd;   // int8 engine: the decode step's matrix inputs as int8 rows + block scales [K / 64][Mq]
     int q_rows = 0;                        // Mq = B rounded up to 16
+    DevBuf mm_h, mm_att, mm_ff;            // int8 engine, dynamic uint8 scheme: (min, max) of the rows of h, of the attention output per head, of the FFN hidden rows per 64 columns
     DevBuf pre_partial;   // K-slice slabs [splits][rows][d_model] of a prefill pass on the skinny kernels
     // audio out
     DevBuf audio;

@@ -261,6 +261,10 @@ struct SkinnyArgs {
     // 1: ONNX DynamicQuantizeLinear per row: uint8 with a zero point over [min(0, min a), max(0, max a)]; needs
     // wsum[splits][N] = per K-slice sums of each weight row (q8_row_sums).
     int q8_act = 0; const int* wsum = nullptr;
+    // scheme 1, optional: the rows' value ranges as their producers left them, a_mm[mm_parts][M][2] = (min, max) of a part of
+    // the row (the product reduces the parts and includes 0); without it the product scans its rows over the full K itself.
+    // c_mm (C form, N % 64 == 0): the ranges of the result rows after the activation, one part per 64 columns, [N / 64][M][2]
+    const float* a_mm = nullptr; int mm_parts = 0; float* c_mm = nullptr;
     int a_frag = 0;                  // A holds two-term bf16 fragments (launch_flow_mod_input's frag form); only where skinny_wide_rows_applies()
     int mtiles = 0;                  // 16-row tiles per workgroup: 1, 2 or 4 (0 = 4)
     int kchunk = 0;                  // K elements staged per step: 128, 256 or 512 (bf16, mtiles <= 2); 0 = 128
@@ -284,6 +288,7 @@ struct AddNormArgs {
     const float* g = nullptr; const float* b = nullptr; float eps = 1e-5f;
     float* H = nullptr; float* H32 = nullptr;
     signed char* Hq = nullptr; float* Hd = nullptr; int Mq = 0;   // y also (or instead of H) as int8 blocks of 64 + scales [D / 64][Mq]
+    float* H_mm = nullptr;                                        // (min, max) of every y row, [M][2]
     const float* dot_w = nullptr; const float* dot_b = nullptr; float* dot_out = nullptr;
     int* pos = nullptr; int pos_delta = 0;
     int M = 0, D = 0;
@@ -304,6 +309,7 @@ struct AttnDecodeArgs {
     const float* cos_tab = nullptr; const float* sin_tab = nullptr; int tab_len = 0;
     float* out = nullptr;
     signed char* out_q = nullptr; float* out_d = nullptr; int Mq = 0;   // instead of out: int8 per (row, head) + scales [heads][Mq]
+    float* out_mm = nullptr;                                            // (min, max) of every (head, row) of out, [heads][M][2]
 };
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
 

@@ -322,6 +322,39 @@ def test_full_int8_dynamic_scheme_parity(full, oracle_mod, tmp_path):
     assert worst <= 1.5 * worst_f and worst <= 3e-1
 
 
+def test_int8_dynamic_step_with_producer_ranges_matches_scanning_products(full, tmp_path):
+    """Dynamic uint8 scheme, decode step: the producers (add & norm, attention, FFN-1 epilogue) leave each row's (min, max)
+    and the products quantise from those, against the same step with every product scanning its rows over the full K
+    (POCKET_TTS_Q8_STAGED=1).  Minimum and maximum are exact, so the two agree bit for bit: 64 rows, ragged contexts,
+    three steps."""
+    import dataclasses
+    import ptts_pack as pp
+    spec = dataclasses.replace(full["spec"], q8_act_scheme=1)
+    _, w = pp.read_pack(full["path"])
+    p_dyn = str(tmp_path / "dyn.ptts")
+    pp.write_pack(p_dyn, spec, w)
+    rng = np.random.default_rng(32)
+    embs = [(rng.standard_normal((5 + (11 * i) % 40, spec.d_model)) * 0.5).astype(np.float32) for i in range(64)]
+    seqs = [np.full((64, spec.latent_dim), np.nan, np.float32)] + [(rng.standard_normal((64, spec.latent_dim)) * 0.7).astype(np.float32) for _ in range(2)]
+    outs = []
+    for scan in (False, True):
+        if scan:
+            os.environ["POCKET_TTS_Q8_STAGED"] = "1"
+        try:
+            eng = full["lib"].Engine(p_dyn, precision="int8", temperature=0.0, lsd_steps=10, max_frames=8)
+            st = eng.state(64)
+            for slot in range(64):
+                eng.lm_prefill(st, slot, embs[slot])
+            outs.append([eng.lm_step(st, sq) for sq in seqs])
+            st.close(); eng.close()
+        finally:
+            os.environ.pop("POCKET_TTS_Q8_STAGED", None)
+    for (c0, e0), (c1, e1) in zip(*outs):
+        np.testing.assert_array_equal(c0, c1)
+        np.testing.assert_array_equal(e0, e1)
+    assert np.isfinite(outs[0][-1][0]).all() and np.abs(outs[0][-1][0]).max() > 0.1
+
+
 def test_flow_head_persistent_form_matches_launch_chain(full):
     """bf16 flow head: the one-launch persistent form (every matrix in registers, workgroups handing row groups to each
     other through L2) against the chain of per-block launches on the same inputs, and both against the oracle on the
