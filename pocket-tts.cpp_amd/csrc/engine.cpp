@@ -251,13 +251,12 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
         }
         bytes = pack_q8_layout(qv, N, K);
         if (wsums && q8_act == 1) {   // weight row sums per K-slice, for every slice count the passes use
-            for (int j = 0; j < 5; ++j) {
-                const int sp = 1 << j;
-                if ((K / 64) % sp) continue;
+            for (int sp = 1; sp <= 16; ++sp) {
+                if ((sp > 8 && sp != 16) || (K / 64) % sp) continue;
                 const std::vector<int> sums = q8_row_sums(qv, N, K, sp);
                 extra_.emplace_back(sums.size() * 4);
                 sync_copy(extra_.back().p, sums.data(), sums.size() * 4, hipMemcpyHostToDevice);
-                wsums[j] = static_cast<const int*>(extra_.back().p);
+                wsums[sp] = static_cast<const int*>(extra_.back().p);
             }
         }
         extra_.emplace_back(bytes.size());
@@ -1027,14 +1026,12 @@ void Engine::transformer(const std::vector<TfLayer>& layers, void* kc, void* vc,
     check_launches("the transformer pass");
 }
 
-// The dynamic uint8 scheme of an int8 product: weight row sums for the product's slice count (a power of two up to 16).
+// The dynamic uint8 scheme of an int8 product: weight row sums for the product's slice count.
 static void bind_q8_act(SkinnyArgs& k, int scheme, const int* const* wsums) {
     if (scheme != 1 || k.wtype != W_I8) return;
-    int j = 0;
-    while ((1 << j) < k.splits && j < 4) ++j;
-    if ((1 << j) != k.splits || !wsums[j]) throw std::runtime_error("int8 product: no weight row sums for this K-slice count");
+    if (k.splits < 1 || k.splits > 16 || !wsums[k.splits]) throw std::runtime_error("int8 product: no weight row sums for this K-slice count");
     k.q8_act = 1;
-    k.wsum = wsums[j];
+    k.wsum = wsums[k.splits];
 }
 
 // K-slices for a split-K product: about 256 deep each, at most 8, dividing K into k-step multiples.

@@ -83,8 +83,9 @@ public:
         const void *qkv, *out, *ff1, *ff2;
         const float *s_qkv = nullptr, *s_out = nullptr, *s_ff1 = nullptr, *s_ff2 = nullptr;
         const void *qkv_lo = nullptr, *out_lo = nullptr, *ff2_lo = nullptr;   // second planes of two-term bf16 matrices (null: one term)
-        // int8 matrices in the dynamic uint8 activation scheme: per K-slice sums of each weight row, for 1, 2, 4, 8 and 16 slices
-        const int *ws_qkv[5] = {}, *ws_out[5] = {}, *ws_ff1[5] = {}, *ws_ff2[5] = {};
+        // int8 matrices in the dynamic uint8 activation scheme: per K-slice sums of each weight row, indexed by the slice count
+        // (1..8 and 16, where that many slices divide K into whole k-steps)
+        const int *ws_qkv[17] = {}, *ws_out[17] = {}, *ws_ff1[17] = {}, *ws_ff2[17] = {};
     };
     int q8_act = 0;   // int8 engine's activation scheme (Spec::q8_act_scheme, POCKET_TTS_Q8_ACT=block|dyn overrides)
     std::set<std::string> two_term;   // matrix families held as two bf16 terms (see two_term_families in engine.cpp)

@@ -61,6 +61,42 @@ def test_lm_prefill_and_steps(ptts, packs, oracle_mod, name, precision, tol):
     st.close(); eng.close()
 
 
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_lm_steps_int8_engine_in_both_activation_schemes(ptts, packs, oracle_mod, tmp_path, scheme):
+    """int8 engine on the small model (K = 256 and 512: one and two K slices) with the activation scheme the pack header
+    names - 0 per row and block of 64, 1 per-row uint8 with a zero point - against the checker in the same scheme on the
+    same weights.  Quantisation is discontinuous, so this is a guard at a few times the flip noise, not a float bound; the
+    product kernels are compared exactly elsewhere."""
+    import dataclasses
+    import ptts_pack as pp
+    _, spec0, w = packs["small"]
+    spec = dataclasses.replace(spec0, q8_act_scheme=scheme)
+    p_eng, p_chk = str(tmp_path / "eng.ptts"), str(tmp_path / "chk.ptts")
+    pp.write_pack(p_eng, spec, w)
+    pp.write_pack(p_chk, spec, pp.int8_model(w, scheme=scheme))
+    eng = ptts.Engine(p_eng, precision="int8")
+    o = oracle_mod.Oracle(p_chk, int8=True)
+    rng = np.random.default_rng(4)
+    B, S = 3, 4
+    embs = [(rng.standard_normal((n, spec.d_model)) * 0.5).astype(np.float32) for n in (11, 6, 17)]
+    seq = rng.standard_normal((S, B, spec.latent_dim)).astype(np.float32)
+    seq[0] = np.nan
+    st = eng.state(B)
+    ost = [o.lm_state(128) for _ in range(B)]
+    for b in range(B):
+        eng.lm_prefill(st, b, embs[b])
+        o.lm_main(ost[b], None, embs[b])
+    worst, scale = 0.0, 0.0
+    for s_ in range(S):
+        cond, eos = eng.lm_step(st, seq[s_])
+        for b in range(B):
+            oc, oe = o.lm_main(ost[b], seq[s_, b:b + 1], None)
+            worst = max(worst, float(np.abs(cond[b] - oc).max()))
+            scale = max(scale, float(np.abs(oc).max()))
+    assert np.isfinite(worst) and worst < 0.1 * scale, (worst, scale)
+    st.close(); eng.close()
+
+
 @pytest.mark.parametrize("precision,tol", [("fp32", F32_TOL), ("bf16", BF16_TOL * 5)])
 def test_lm_steps_long_ragged_context(ptts, packs, oracle_mod, precision, tol):
     """Decode attention beyond 64 keys per wave (a bf16 cache walks its range in blocks of 64 with a running softmax):
