@@ -39,7 +39,7 @@ walks the nodes in graph order and gives every pack tensor of that graph (in the
 not yet taken, of a tensor whose shape fits (as stored, transposed, or as a Conv1d weight).  The consuming node settles
 what shapes cannot: a MatMul's second input is [in][out] and is transposed even when square.  Separate q / k / v matrices
 become one "concat" entry, Constant-node tensors count like initializers, a tensor consumed by two nodes may serve two pack
-tensors ("shared_with").  Guesses the file does not settle carry a "note"; what cannot be placed is listed under
+tensors ("shared_with"), a square quantised matrix gets its scale axis from its consumer ("axis").  Guesses the file does not settle carry a "note"; what cannot be placed is listed under
 "unresolved" with the shapes still free in that file.  The draft is for a person to review against `--list`: shapes
 repeat from layer to layer, and only the order of the graph tells them apart.
 
@@ -232,6 +232,8 @@ def guess_map(models_dir, spec, int8=False):
     files = open_all(models_dir)
     order = {fn: consumption_order(ow) for fn, ow in files.items()}
     tensors, unresolved = {}, []
+    nscales = {fn: {nm[:-len("_scale")]: int(np.prod(info[2])) if info[2] else 1 for nm, info in ow.info.items() if nm.endswith("_scale")}
+               for fn, ow in files.items()}     # quantised triplets: how many scales each has
     used = {fn: set() for fn in files}          # indices into order[fn]
     owner = {fn: {} for fn in files}            # tensor name -> pack tensor that took it first
     squeeze = lambda t: tuple(d for d in t if d != 1)
@@ -241,10 +243,16 @@ def guess_map(models_dir, spec, int8=False):
         base, have, op, pos = ev
         ent = {"file": fn, "tensor": base, "guessed": True}
         matmul_b = op in ("MatMul", "MatMulInteger") and pos == 1
+        if len(have) == 2 and have[0] == have[1] and nscales[fn].get(base, 1) == have[0]:
+            # a square quantised matrix with one scale per row or column: the shapes do not say which.  Per-channel
+            # quantisation of a MatMul weight [in][out] runs along its output axis (1); a Gemm weight [out][in] along 0.
+            ent["axis"] = 1 if matmul_b else 0
+            if not matmul_b and op != "Gemm":
+                ent["note"] = "square quantised matrix and no MatMul/Gemm consumer: scale axis and orientation unknown"
         if len(want) == 2 and len(have) == 2 and have[0] == have[1] == want[0] == want[1]:
             if matmul_b:
                 ent["transpose"] = True
-            elif op not in ("Gemm",):
+            elif op not in ("Gemm",) and "note" not in ent:
                 ent["note"] = "square matrix and no MatMul/Gemm consumer: stored orientation unknown"
             return ent
         if have == want or squeeze(have) == squeeze(want):

@@ -356,3 +356,57 @@ def test_guess_map_lists_what_it_cannot_place(tmp_path, packs, ponnx):
     assert u["file"] == "flow_lm_flow.onnx" and u["shape"] == [spec.flow_dim, spec.flow_dim] and u["pack_tensor"].startswith("flow.")
     assert [spec.flow_dim, spec.flow_dim] not in u["free_shapes_in_file"]
     assert all(n in tensors for n, _, _ in pp.tensor_table(spec) if not n.startswith("flow."))
+
+
+def test_guess_map_on_a_dynamically_quantised_graph(tmp_path, packs, ponnx):
+    """The `_int8` graphs as ONNX Runtime's dynamic quantisation writes them: every LM-layer matrix a `_quantized` / `_scale` /
+    `_zero_point` triplet stored [in][out] and consumed by a MatMulInteger behind a DynamicQuantizeLinear.  `--guess --int8`
+    places the triplets by their base names (transposed, being a MatMulInteger's second input), and converting with the
+    draft carries the integers into the pack and marks it for per-row uint8 activations."""
+    import onnx_to_ptts
+    import ptts_pack as pp
+    path, spec, w = packs["tiny"]
+    mdir = tmp_path / "onnx"
+    mdir.mkdir()
+    per_file, nodes, want_q8 = {}, {}, {}
+    for k, (name, shape, _) in enumerate(pp.tensor_table(spec)):
+        a = w[name]
+        fn = onnx_to_ptts.graph_file(name, int8=True)
+        inits, nds = per_file.setdefault(fn, []), nodes.setdefault(fn, [])
+        t = f"onnx::MatMul_{900 + k}"
+        if pp.is_int8_weight(name, spec.flow_dim, scheme=1):
+            q, sc, z = ow.quantize_per_axis(np.ascontiguousarray(a.T), 1)
+            inits += [ow.tensor(t + "_quantized", q), ow.tensor(t + "_scale", sc), ow.tensor(t + "_zero_point", z)]
+            nds += [ow.node("DynamicQuantizeLinear", [f"act_{k}"], [f"act_{k}_q", f"act_{k}_s", f"act_{k}_z"]),
+                    ow.node("MatMulInteger", [f"act_{k}_q", t + "_quantized", f"act_{k}_z", t + "_zero_point"], [f"acc_{k}"])]
+            want_q8[name] = (np.ascontiguousarray(q.T), sc)
+        elif a.ndim == 2 and name.endswith(".w") and name.startswith(("lm.", "flow.")):
+            inits.append(ow.tensor(t, np.ascontiguousarray(a.T)))
+            nds.append(ow.node("MatMul", [f"act_{k}", t], [f"act_{k + 1}"]))
+        elif name in ("dec.conv0.w", "enc.conv0.w"):
+            inits.append(ow.tensor(t, np.ascontiguousarray(a.reshape(a.shape[0], spec.kernel, -1).transpose(0, 2, 1))))
+            nds.append(ow.node("Conv", [f"act_{k}", t], [f"act_{k + 1}"]))
+        else:
+            inits.append(ow.tensor(t, a))
+            nds.append(ow.node("Conv" if a.ndim == 2 else "Add", [f"act_{k}", t], [f"act_{k + 1}"]))
+    for fn in per_file:
+        (mdir / fn).write_bytes(ow.model(per_file[fn][::-1], nodes[fn]))
+    assert "flow_lm_main_int8.onnx" in per_file and want_q8
+    tensors, unresolved = onnx_to_ptts.guess_map(str(mdir), spec, int8=True)
+    assert not unresolved
+    for name in want_q8:
+        assert tensors[name].get("transpose") and tensors[name]["file"] == "flow_lm_main_int8.onnx", name
+    spec_kw = {f: getattr(spec, f) for f in pp.SPEC_INT_FIELDS + pp.SPEC_FLOAT_FIELDS if f != "q8_act_scheme"}
+    (tmp_path / "draft.json").write_text(json.dumps({"spec": spec_kw, "tensors": tensors}))
+    out = str(tmp_path / "int8.ptts")
+    got_spec, w2 = onnx_to_ptts.convert(str(mdir), out, str(tmp_path / "draft.json"))
+    assert got_spec.q8_act_scheme == 1
+    carried = pp.read_pack_q8(out)
+    assert sorted(carried) == sorted(want_q8)
+    for name, (q, sc) in want_q8.items():
+        np.testing.assert_array_equal(carried[name][0], q, err_msg=name)
+        np.testing.assert_array_equal(carried[name][1], sc, err_msg=name)
+        np.testing.assert_array_equal(w2[name], q.astype(np.float32) * sc[:, None], err_msg=name)
+    for name in w:
+        if name not in want_q8:
+            np.testing.assert_array_equal(w2[name], w[name], err_msg=name)
