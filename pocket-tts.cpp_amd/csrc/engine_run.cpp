@@ -303,6 +303,9 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
         times_.head_ms += hd; times_.head_calls += flow_head_launch_count(fa);
     };
 
+    // frames per decoder call of the batch (at most 15, src/pocket_tts.cpp:461; the decoder is streaming, so any chunking gives
+    // the same samples)
+    static const int dec_every = [] { const char* e = std::getenv("POCKET_TTS_DEC_CHUNK"); const int v = e ? std::atoi(e) : kDecChunk; return v >= 1 && v <= kDecChunk ? v : kDecChunk; }();
     size_t n_finished = 0;
     FlagWait flag_wait;
     auto last_progress = std::chrono::steady_clock::now();   // several parts are polled in turn: none may stall for longer than the wait limit
@@ -343,8 +346,8 @@ void Engine::run_staged(Job& job, std::vector<int>& frames_out, std::vector<std:
                 // Every full 15-frame chunk goes to the decoder as soon as its latents are queued: the decoder never
                 // feeds back into the frame loop (the reference decodes after the loop, :640; the chunk boundaries
                 // and the carried state are the same).
-                if ((step + 1) % kDecChunk == 0) {
-                    decode_chunk(r, step + 1 - kDecChunk, kDecChunk);
+                if ((step + 1) % dec_every == 0) {
+                    decode_chunk(r, step + 1 - dec_every, dec_every);
                     r.decoded = step + 1;
                 }
                 r.step = step + 1;
