@@ -35,6 +35,7 @@ def lib() -> C.CDLL:
         L.ptts_oracle_load.argtypes = [C.c_char_p]
         L.ptts_oracle_free.argtypes = [C.c_void_p]
         L.ptts_oracle_enable_q8.argtypes = [C.c_void_p]
+        L.ptts_oracle_enable_q8_ex.argtypes = [C.c_void_p, C.c_int]
         L.ptts_oracle_q8_linear.argtypes = [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int, f32p]
         L.ptts_oracle_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.ptts_oracle_text_conditioner.argtypes = [C.c_void_p, i64p, C.c_int, f32p]
@@ -78,14 +79,14 @@ def _ptr(a):
 class Oracle:
     """One loaded weight pack plus the five graph functions and the orchestration."""
 
-    def __init__(self, pack_path: str, int8: bool = False):
+    def __init__(self, pack_path: str, int8: bool = False, q8_flow: bool = False):
         self.L = lib()
         self.h = self.L.ptts_oracle_load(pack_path.encode())
         if not self.h:
             raise RuntimeError(f"oracle: cannot load pack {pack_path}")
-        if int8:   # LM-layer and flow-block matrices in the engine's int8 scheme (see ptts_oracle.c, linear_q8); the
-            # activation scheme is the pack's (Spec.q8_act_scheme)
-            self.L.ptts_oracle_enable_q8(self.h)
+        if int8:   # LM-layer matrices (q8_flow: and the flow blocks', as an engine with POCKET_TTS_Q8_FLOW=1 holds them) in the
+            # engine's int8 scheme (see ptts_oracle.c, linear_q8); the activation scheme is the pack's (Spec.q8_act_scheme)
+            self.L.ptts_oracle_enable_q8_ex(self.h, 1 if q8_flow else 0)
         d = (C.c_int * 6)()
         self.L.ptts_oracle_dims(self.h, d)
         self.latent, self.d_model, self.frame_size, self.vocab, self.mimi_dim, self.sample_rate = list(d)

@@ -151,14 +151,15 @@ void ptts_oracle_enable_q8_some(Oracle *o, int mask) {
 static int g_q8_act = 0;
 void ptts_oracle_set_q8_act(int scheme) { g_q8_act = scheme; }
 
-/* ... all of them: the int8 engine's scheme.  In the dynamic uint8 scheme the flow blocks keep their bf16 matrices (the
- * engine's persistent flow head quantises per block of 64 only), and the scheme is taken from the pack header. */
-void ptts_oracle_enable_q8(Oracle *o) {
+/* The int8 engine's model: the LM layers' matrices in int8 and, with flow_blocks (the engine's POCKET_TTS_Q8_FLOW=1; per-block
+ * scheme only), the flow blocks' too.  The activation scheme is taken from the pack header. */
+void ptts_oracle_enable_q8_ex(Oracle *o, int flow_blocks) {
     const int saved = g_q8_act;
     g_q8_act = o->s.q8_act_scheme;
-    ptts_oracle_enable_q8_some(o, g_q8_act == 1 ? 15 : 63);
+    ptts_oracle_enable_q8_some(o, (flow_blocks && g_q8_act == 0) ? 63 : 15);
     g_q8_act = saved;
 }
+void ptts_oracle_enable_q8(Oracle *o) { ptts_oracle_enable_q8_ex(o, 0); }
 
 /* Attribution knob (tools/int8_attribution.py): which side of an int8 product is quantised.  3 = both (the engine's
  * scheme, the default), 1 = weights only (activations stay float32), 2 = activations only (weights stay float32). */

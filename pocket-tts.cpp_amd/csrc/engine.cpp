@@ -206,8 +206,11 @@ Model::Model(const Pack& pack, Precision prec) : spec_(pack.spec()), prec_(prec)
     q8_act = s.q8_act_scheme == 1 ? 1 : 0;
     if (const char* e = std::getenv("POCKET_TTS_Q8_ACT")) q8_act = std::string(e) == "dyn" ? 1 : 0;
     if (!q8) q8_act = 0;
-    // narrower heads keep bf16 blocks; so does the dynamic uint8 scheme (the persistent head quantises per block of 64 only)
-    flow_block_wtype = (q8 && q8_act == 0 && s.flow_dim % 256 == 0) ? W_I8 : flow_wtype;
+    // The int8 engine's flow blocks are bf16 unless POCKET_TTS_Q8_FLOW=1 asks for int8 blocks too (per-block scheme, flow_dim a
+    // multiple of 256): measured on the 64 x 125 workload the int8 head is slower than the bf16 one (0.369 against 0.336 ms per
+    // launch, 6156 against 6416 RTFx) and farther from the float model, so int8 blocks are an option, not the default.
+    const bool q8_flow = [] { const char* e = std::getenv("POCKET_TTS_Q8_FLOW"); return e && std::atoi(e) != 0; }();
+    flow_block_wtype = (q8 && q8_flow && q8_act == 0 && s.flow_dim % 256 == 0) ? W_I8 : flow_wtype;
     two_term = two_term_families(prec_, flow_block_wtype == W_I8);
     // second plane of a two-term matrix in the fragment-major layout of the skinny / flow kernels
     auto packed_lo = [&](const float* W, int N, int K) -> const void* {

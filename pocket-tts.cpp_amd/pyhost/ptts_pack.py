@@ -349,7 +349,8 @@ def bf16_round(a: np.ndarray) -> np.ndarray:
 
 
 # Matrix families the bf16 engine keeps as two bf16 terms (~16 mantissa bits, float-grade) by default; the int8 engine
-# keeps the first three (its LM layer matrices are int8 and its flow head has no room for second planes).
+# keeps the same five, or only the first three when its flow blocks are int8 as well (POCKET_TTS_Q8_FLOW=1: that flow head
+# has no room for second planes).
 # Mirrors two_term_families() in csrc/engine.cpp.
 TWO_TERM_DEFAULT = ("lm.in_proj", "flow.cond", "flow.ada", "flow.in_proj", "flow.final.lin")
 
@@ -376,23 +377,24 @@ def bf16_model(weights: Dict[str, np.ndarray], two_term=TWO_TERM_DEFAULT) -> Dic
     return {k: (bf16_round(v) if rounded(k) else v) for k, v in weights.items()}
 
 
-def is_int8_weight(name: str, flow_dim: int = 512, scheme: int = 0) -> bool:
-    """Matrices the int8 engine holds as int8 (per-output-channel scale): LM layers and, when flow_dim is a
-    multiple of 256 and the activation scheme is the per-block one (scheme 0), the flow residual blocks."""
+def is_int8_weight(name: str, flow_dim: int = 512, scheme: int = 0, flow_blocks: bool = False) -> bool:
+    """Matrices the int8 engine holds as int8 (per-output-channel scale): the LM layers and, with flow_blocks
+    (POCKET_TTS_Q8_FLOW=1 on the engine), flow_dim a multiple of 256 and the per-block activation scheme (scheme 0),
+    the flow residual blocks."""
     if name.startswith("lm.l") and name.endswith((".qkv.w", ".out.w", ".ff1.w", ".ff2.w")):
         return True
-    return scheme == 0 and flow_dim % 256 == 0 and name.startswith("flow.b") and name.endswith((".fc1.w", ".fc2.w"))
+    return flow_blocks and scheme == 0 and flow_dim % 256 == 0 and name.startswith("flow.b") and name.endswith((".fc1.w", ".fc2.w"))
 
 
-def int8_model(weights: Dict[str, np.ndarray], scheme: int = 0) -> Dict[str, np.ndarray]:
+def int8_model(weights: Dict[str, np.ndarray], scheme: int = 0, flow_blocks: bool = False) -> Dict[str, np.ndarray]:
     """Weight set for checking the int8 engine: like bf16_model, except that the matrices the engine quantises
     to int8 stay float32 here (both sides derive the int8 values and scales from the same float32 numbers).
-    scheme = Spec.q8_act_scheme of the pack the weights go into."""
+    scheme = Spec.q8_act_scheme of the pack the weights go into; flow_blocks = the engine runs with POCKET_TTS_Q8_FLOW=1."""
     flow_dim = weights["flow.in_proj.w"].shape[0]
-    blocks_q8 = scheme == 0 and flow_dim % 256 == 0
+    blocks_q8 = flow_blocks and scheme == 0 and flow_dim % 256 == 0
     q = bf16_model(weights, two_term=TWO_TERM_DEFAULT[:3] if blocks_q8 else TWO_TERM_DEFAULT)
     for k, v in weights.items():
-        if is_int8_weight(k, flow_dim, scheme):
+        if is_int8_weight(k, flow_dim, scheme, flow_blocks):
             q[k] = v
     return q
 

@@ -1,8 +1,8 @@
 """Which part of the int8 scheme owns the int8 engine's distance from the float32 model?  CPU only (uses the checker
 under oracle/: a diagnostic beside the tests, never part of the product path).
 
-The int8 engine = the bf16 engine with the LM layers' qkv / out / ff1 / ff2 and the flow blocks' fc1 / fc2 as int8 rows
-(one scale per output row) multiplied with activations quantised per row and 64-wide block.  The float32 checker can
+The int8 engine = the bf16 engine with the LM layers' qkv / out / ff1 / ff2 (and, with POCKET_TTS_Q8_FLOW=1, the flow blocks'
+fc1 / fc2) as int8 rows (one scale per output row) multiplied with activations quantised per row and 64-wide block.  The float32 checker can
 apply that scheme to any subset of the six families and to either side alone (weights only / activations only), so each
 row below is the float32 model with ONE such quantity quantised, against the float32 model, per-frame latents on the same
 history (the inputs of tests/test_gpu_configs.py::test_scaled_pack_int8_vs_float32_oracle).
@@ -75,6 +75,8 @@ def main():
     pp.write_pack(path, spec, w)
     path_e = os.path.join(tmp, "engine.ptts")
     pp.write_pack(path_e, spec, pp.int8_model(w, scheme=spec.q8_act_scheme))   # what the int8 engine holds beside its int8 matrices
+    path_ef = os.path.join(tmp, "engine_flow.ptts")
+    pp.write_pack(path_ef, spec, pp.int8_model(w, scheme=spec.q8_act_scheme, flow_blocks=True))   # ... with POCKET_TTS_Q8_FLOW=1
 
     def run(pack, mask, parts, kv=False, base=None):
         o = oracle_py.Oracle(pack)
@@ -122,11 +124,12 @@ def main():
         report("all six families: weights and activations", run(path, 63, 3, base=base))
         report("LM families only (flow blocks float32): both sides", run(path, 15, 3, base=base))
         report("flow blocks only (LM float32): both sides", run(path, 48, 3, base=base))
-        report("the int8 engine's whole model (+ bf16 rest, bf16 K/V)", run(path_e, 63, 3, kv=True, base=base))
+        report("the int8 engine's whole model (int8 LM layers + bf16 rest, bf16 K/V)", run(path_e, 15, 3, kv=True, base=base))
+        report("... with int8 flow blocks as well (POCKET_TTS_Q8_FLOW=1)", run(path_ef, 63, 3, kv=True, base=base))
     if a.out:
         with open(a.out, "w") as f:
             f.write("\n".join(lines) + "\n")
-    for p in (path, path_e):
+    for p in (path, path_e, path_ef):
         os.remove(p)
     os.rmdir(tmp)
 

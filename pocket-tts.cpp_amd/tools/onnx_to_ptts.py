@@ -20,8 +20,8 @@ Per entry: `transpose` swaps a 2-D matrix to [out][in]; `conv` turns a Conv1d we
 (q - zero_point) * scale with `axis` (default: the axis the scales fit); `rows: [a, b]` keeps rows a..b-1;
 `reshape` forces the final shape.
 
-Matrices that the int8 engine multiplies in int8 (`ptts_pack.is_int8_weight`: the LM layers' qkv / out / ff1 / ff2 and the
-flow blocks' fc1 / fc2) and that arrive as a `_quantized` / `_scale` / `_zero_point` triplet are carried into the pack as
+Matrices that the int8 engine multiplies in int8 (`ptts_pack.is_int8_weight`: the LM layers' qkv / out / ff1 / ff2 and, for
+engines started with POCKET_TTS_Q8_FLOW=1, the flow blocks' fc1 / fc2) and that arrive as a `_quantized` / `_scale` / `_zero_point` triplet are carried into the pack as
 they are — int8 values (q - zero_point) and one scale per output row, next to the dequantised f32 tensor — whenever the
 triplet allows it: scale per tensor or per output channel, q - zero_point within int8.  The int8 engine then multiplies
 with the source's own integers; other triplets are only dequantised.
@@ -325,7 +325,7 @@ def convert(models_dir, out_path, map_path=None, auto=False, spec_over=None):
             spec = dataclasses.replace(spec, q8_act_scheme=1)
     q8 = {}
     for name, shape, _ in table:
-        if pp.is_int8_weight(name, spec.flow_dim, spec.q8_act_scheme):
+        if pp.is_int8_weight(name, spec.flow_dim, spec.q8_act_scheme, flow_blocks=True):   # flow blocks: for POCKET_TTS_Q8_FLOW=1
             got = fetch_q8(files, tensors[name], shape)
             if got is not None:
                 q8[name] = got

@@ -198,7 +198,7 @@ def test_converter_reads_the_activation_scheme_off_the_graph(tmp_path, packs, po
             a = w[name]
             fn = _graph_of(name)
             ent = {"file": fn, "tensor": f"t{k}"}
-            if pp.is_int8_weight(name, spec.flow_dim):
+            if pp.is_int8_weight(name, spec.flow_dim, flow_blocks=True):
                 q, sc, z = ow.quantize_per_axis(np.ascontiguousarray(a.T), 1)
                 per_file.setdefault(fn, []).extend([ow.tensor(f"t{k}_quantized", q), ow.tensor(f"t{k}_scale", sc), ow.tensor(f"t{k}_zero_point", z)])
                 ent.update(transpose=True, axis=1)
@@ -220,7 +220,7 @@ def test_converter_reads_the_activation_scheme_off_the_graph(tmp_path, packs, po
         return str(mdir), mapping
 
     lm_q8 = sorted(n for n, _, _ in pp.tensor_table(spec) if n.startswith("lm.l") and pp.is_int8_weight(n, spec.flow_dim))
-    all_q8 = sorted(n for n, _, _ in pp.tensor_table(spec) if pp.is_int8_weight(n, spec.flow_dim))
+    all_q8 = sorted(n for n, _, _ in pp.tensor_table(spec) if pp.is_int8_weight(n, spec.flow_dim, flow_blocks=True))
     assert len(all_q8) > len(lm_q8) > 0
     out = str(tmp_path / "out.ptts")
     for tag, with_nodes, over, scheme, carried in [("dyn", True, {}, 1, lm_q8), ("plain", False, {}, 0, all_q8),

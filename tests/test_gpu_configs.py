@@ -286,7 +286,7 @@ def test_scaled_pack_bf16_vs_float32_oracle(env):
 # model the int8 engine sits near 1e-1 whatever the activations do (profiles/r03_int8_attribution.txt).  Whether a trained
 # checkpoint stays inside 2e-2 cannot be measured offline; the test is an expected failure that reports, not an assertion
 # moved to where it passes.
-@pytest.mark.xfail(reason="int8 weights + dynamic int8 activations on a random-weight model: about 1e-1 measured against the 2e-2 specification",
+@pytest.mark.xfail(reason="int8 weights + dynamic int8 activations on a random-weight model: 6e-2 to 1e-1 measured against the 2e-2 specification",
                    strict=False)
 def test_scaled_pack_int8_vs_float32_oracle(env):
     assert _scaled_pack_error(env, "int8") <= 2e-2

@@ -122,11 +122,25 @@ def test_full_batch64_bench_shape(full):
     eng.close()
 
 
-def test_full_int8_graphs_and_offline_parity(full):
-    """int8 engine (int8 LM-layer and flow-block matrices on v_mfma_i32, block-quantised activations) against the
-    oracle running the same quantisation scheme on the same weights: graph by graph, then per frame."""
-    eng = full["lib"].Engine(full["path"], precision="int8", temperature=0.0, lsd_steps=10, max_frames=F)
-    o8, spec = full["oi8"], full["spec"]
+@pytest.mark.parametrize("q8_flow", [False, True])
+def test_full_int8_graphs_and_offline_parity(full, oracle_mod, tmp_path, q8_flow):
+    """int8 engine (int8 LM-layer matrices on v_mfma_i32, block-quantised activations; q8_flow: the flow blocks in int8 as
+    well, POCKET_TTS_Q8_FLOW=1, the persistent head's int8 form) against the oracle running the same quantisation scheme on
+    the same weights: graph by graph, then per frame."""
+    import ptts_pack as pp
+    spec = full["spec"]
+    if q8_flow:
+        _, w = pp.read_pack(full["path"])
+        p_chk = str(tmp_path / "int8_flow.ptts")
+        pp.write_pack(p_chk, spec, pp.int8_model(w, flow_blocks=True))
+        o8 = oracle_mod.Oracle(p_chk, int8=True, q8_flow=True)
+        os.environ["POCKET_TTS_Q8_FLOW"] = "1"
+    else:
+        o8 = full["oi8"]
+    try:
+        eng = full["lib"].Engine(full["path"], precision="int8", temperature=0.0, lsd_steps=10, max_frames=F)
+    finally:
+        os.environ.pop("POCKET_TTS_Q8_FLOW", None)
     rng = np.random.default_rng(5)
     # flow head alone
     cond = rng.standard_normal((3, spec.d_model)).astype(np.float32)
@@ -158,7 +172,7 @@ def test_full_int8_graphs_and_offline_parity(full):
         assert res[i]["frames"] == frames == F
         worst = max(worst, float(np.abs(res[i]["latents"] - lat8).max()))
         worst_f = max(worst_f, float(np.abs(res[i]["latents"] - latf).max()))
-    _note(f"int8 full size: flow head max-abs {e_flow:.3e}, LM cond/eos max-abs {e_lm:.3e}, per-frame latent max-abs vs int8 oracle "
+    _note(f"int8 full size{' (int8 flow blocks)' if q8_flow else ''}: flow head max-abs {e_flow:.3e}, LM cond/eos max-abs {e_lm:.3e}, per-frame latent max-abs vs int8 oracle "
           f"{worst:.3e}, vs f32 oracle {worst_f:.3e}")
     # Dynamic activation quantisation is discontinuous: the int8 ORACLE moves by ~4e-2 (LM conditioning, magnitude
     # ~3.5) and ~1e-2 (flow head) when its inputs are perturbed by 1e-6, because a handful of roundings flip.  Two
