@@ -3,6 +3,7 @@
 // Interface contract: /root/reference/include/pocket_tts/pocket_tts.hpp:78-163; the behaviour of each
 // method follows /root/reference/src/pocket_tts.cpp (encodeVoice :241-297, generate :548-657,
 // generateWithEmbeddings :676-684, generateStreaming :686-979, cancelStreaming :981-983).
+#include <cstdlib>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -49,6 +50,14 @@ struct PocketTTS::Impl {
         o.max_frames = cfg.maxFrames;
         o.frames_after_eos = cfg.framesAfterEos;
         o.temperature = cfg.temperature;
+        // POCKET_TTS_TEMPERATURE overrides the configured value: the reference's C API applies the field only when > 0
+        // (src/pocket_tts_c.cpp:33-40), so this is how a caller of the unchanged bindings gets temperature 0 (deterministic runs)
+        if (const char* e = std::getenv("POCKET_TTS_TEMPERATURE")) {
+            char* end = nullptr;
+            const float t = std::strtof(e, &end);
+            if (end == e || !(t >= 0.0f)) throw std::runtime_error(std::string("POCKET_TTS_TEMPERATURE is not a non-negative number: ") + e);
+            o.temperature = t;
+        }
         o.max_text_tokens = cfg.maxTextTokens;
         o.seed = cfg.seed;
         o.has_seed = cfg.hasSeed;

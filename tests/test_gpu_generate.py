@@ -181,3 +181,36 @@ def test_error_conventions(ptts, packs):
     L.pocket_tts_destroy(None)
     L.pocket_tts_free_voice(None)
     L.pocket_tts_cancel_streaming(None)
+
+
+def test_temperature_override_from_the_environment(ptts, packs):
+    """POCKET_TTS_TEMPERATURE replaces the configured temperature when the handle is created: the reference's C API cannot
+    pass 0 (fields are applied only when > 0, src/pocket_tts_c.cpp:33-40), so callers of the unchanged bindings get
+    deterministic runs this way.  With the override at 0 two handles with different seeds agree bit for bit; without it
+    (temperature 0.7) they do not; a value that is not a number fails the creation with a message."""
+    import os
+    path, spec, _ = packs["tiny"]
+    rng = np.random.default_rng(8)
+    ids = [rng.integers(0, spec.vocab, 6).astype(np.int64)]
+    voices = [(rng.standard_normal((4, spec.d_model)) * 0.5).astype(np.float32)]
+
+    def run(seed):
+        eng = ptts.Engine(path, precision="fp32", temperature=0.7, lsd_steps=4, max_frames=5, seed=seed)
+        out = eng.generate_ids(ids, voices)[0]["latents"].copy()
+        eng.close()
+        return out
+
+    a, b = run(1), run(2)
+    assert np.abs(a - b).max() > 1e-3
+    os.environ["POCKET_TTS_TEMPERATURE"] = "0"
+    try:
+        c, d = run(1), run(2)
+    finally:
+        os.environ.pop("POCKET_TTS_TEMPERATURE", None)
+    np.testing.assert_array_equal(c, d)
+    os.environ["POCKET_TTS_TEMPERATURE"] = "warm"
+    try:
+        with pytest.raises(ptts.PttsError, match="POCKET_TTS_TEMPERATURE"):
+            run(1)
+    finally:
+        os.environ.pop("POCKET_TTS_TEMPERATURE", None)
