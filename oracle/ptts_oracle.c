@@ -200,7 +200,11 @@ static const Q8Entry *q8_find(const float *W) {
 }
 
 static void q8_register(const float *W, int N, int K) {
-    if (q8_find(W) || g_nq8 >= 128 || K % 64) return;
+    if (q8_find(W) || K % 64) return;
+    if (g_nq8 >= 128) {   /* a matrix silently left in float would look like a parity error of the engine */
+        fprintf(stderr, "ptts_oracle: more than 128 int8 matrices registered at once\n");
+        abort();
+    }
     Q8Entry *e = &g_q8[g_nq8];
     e->W = W; e->N = N; e->K = K; e->act = g_q8_act;
     e->q = (int8_t *)malloc((size_t)N * K);
